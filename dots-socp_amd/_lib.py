@@ -1,0 +1,134 @@
+"""ctypes binding of libdotsocp_hip.so (declarations mirror include/dots_socp_hip.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load, every entry point of
+the package that needs it raises ``HipLibraryError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libdotsocp_hip.so")
+ABI_VERSION = 1
+
+ARRAY_IDS = {
+    "phi": 0, "A": 1, "B": 2, "lambda_c": 3, "z_fst": 4, "z_mid": 5, "z_end": 6,
+    "mu": 7, "E": 8, "beta_fst": 9, "beta_mid": 10, "beta_end": 11,
+}
+LAP_SOLVERS = {"spacetime_pcg": 0, "modal_pcg": 1}
+PHASES = {"laplacian": 0, "soc_projection": 1, "q_lambda_mult": 2}
+OPERATORS = {
+    "grad_time": 0, "div_time": 1, "grad_space": 2, "div_space": 3, "decouple": 4,
+    "decouple_adjoint": 5, "time_avg_adjoint": 6, "laplacian_apply": 7,
+}
+EXPORTS = [
+    "dots_abi_version", "dots_last_error", "dots_create", "dots_destroy", "dots_set_params", "dots_get_params",
+    "dots_sync", "dots_upload", "dots_download", "dots_array_count", "dots_step", "dots_run_phase", "dots_kkt",
+    "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
+    "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes",
+]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("n_time", C.c_int32), ("n_vertices", C.c_int32),
+        ("n_triangles", C.c_int32), ("n_corners", C.c_int32), ("lap_nnz", C.c_int32), ("lap_solver", C.c_int32),
+        ("triangles", _i32p), ("hat_grad", _f64p), ("area_tri", _f64p), ("mass_vert", _f64p),
+        ("corner_ptr", _i32p), ("corner_idx", _i32p), ("lap_rowptr", _i32p), ("lap_col", _i32p), ("lap_val", _f64p),
+        ("mu0", _f64p), ("mu1", _f64p), ("perm_vert", _i32p), ("perm_tri", _i32p),
+        ("time_modes", _f64p), ("time_eigs", _f64p),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("r", C.c_double), ("scale_z", C.c_double), ("const_d", C.c_double), ("norm_d", C.c_double),
+        ("norm_boundary", C.c_double), ("congestion", C.c_double), ("tau", C.c_double), ("eps", C.c_double),
+        ("prim_scale", C.c_double), ("dual_scale", C.c_double), ("boundary_scale", C.c_double), ("cg_tol", C.c_double),
+        ("cg_max_iter", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class StepStats(C.Structure):
+    _fields_ = [
+        ("alm_iterations", C.c_int32), ("cg_iterations", C.c_int32), ("cg_last_iterations", C.c_int32),
+        ("cg_not_converged", C.c_int32), ("cg_last_rel_residual", C.c_double),
+        ("ms_rhs", C.c_double), ("ms_laplacian", C.c_double), ("ms_soc", C.c_double),
+        ("ms_q_lambda_multiplier", C.c_double), ("ms_total", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library (once) and declare the signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m dots_socp_amd.build` (hipcc, gfx950). "
+            "dots-socp_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    missing = [n for n in EXPORTS if not hasattr(lib, n)]
+    if missing:
+        raise HipLibraryError(f"{LIB_PATH} does not export {missing}")
+    vp = C.c_void_p
+    lib.dots_abi_version.restype = C.c_int
+    lib.dots_last_error.restype = C.c_char_p
+    lib.dots_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(vp)]
+    lib.dots_destroy.argtypes = [vp]
+    lib.dots_set_params.argtypes = [vp, C.POINTER(Params)]
+    lib.dots_get_params.argtypes = [vp, C.POINTER(Params)]
+    lib.dots_sync.argtypes = [vp]
+    lib.dots_upload.argtypes = [vp, C.c_int, _f64p, C.c_int64]
+    lib.dots_download.argtypes = [vp, C.c_int, _f64p, C.c_int64]
+    lib.dots_array_count.argtypes = [vp, C.c_int]
+    lib.dots_array_count.restype = C.c_int64
+    lib.dots_step.argtypes = [vp, C.c_int, C.POINTER(StepStats)]
+    lib.dots_run_phase.argtypes = [vp, C.c_int, C.POINTER(StepStats)]
+    lib.dots_kkt.argtypes = [vp, C.c_uint32, _f64p]
+    lib.dots_objective.argtypes = [vp, _f64p]
+    lib.dots_adjust_penalty.argtypes = [vp, C.c_double]
+    lib.dots_scale_z.argtypes = [vp, C.c_double, C.c_double, C.c_double]
+    lib.dots_scale_arrays.argtypes = [vp, C.c_uint32, C.c_double]
+    lib.dots_norm_square.argtypes = [vp, C.c_int, C.c_int, _f64p]
+    lib.dots_apply_operator.argtypes = [vp, C.c_int, C.c_double, _f64p, C.c_int64, _f64p, C.c_int64]
+    lib.dots_bench_kernel.argtypes = [vp, C.c_int, C.c_int, _f64p, _f64p]
+    lib.dots_device_bytes.argtypes = [vp]
+    lib.dots_device_bytes.restype = C.c_int64
+    for n in EXPORTS:
+        f = getattr(lib, n)
+        if n not in ("dots_last_error", "dots_array_count", "dots_device_bytes"):
+            f.restype = C.c_int
+    if lib.dots_abi_version() != ABI_VERSION:
+        raise HipLibraryError("libdotsocp_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().dots_last_error().decode("utf-8", "replace")
+        raise HipLibraryError(f"{what or 'libdotsocp_hip'} failed with status {rc}: {msg}")

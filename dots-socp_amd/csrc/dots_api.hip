@@ -1,0 +1,442 @@
+// C ABI of libdotsocp_hip.so (see include/dots_socp_hip.h): context lifecycle, state transfer,
+// the ALM step driver.  Everything here is host code around the kernels of kernels_*.hip.
+#include "dots_dev.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+struct dots_ctx : dots::Ctx {};
+
+namespace dots {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    set_error(buf);
+    return DOTS_ERR_HIP;
+}
+
+int array_kind(int id) {
+    switch (id) {
+        case DOTS_PHI: return 0;
+        case DOTS_B: case DOTS_E: return 2;
+        case DOTS_Z_MID: case DOTS_BETA_MID: return 3;
+        default: return 1;
+    }
+}
+int64_t array_count_host(const Dev &d, int id) {
+    switch (array_kind(id)) {
+        case 0: return (int64_t)(d.T + 1) * d.V;
+        case 1: return (int64_t)d.T * d.V;
+        case 2: return (int64_t)(d.T + 1) * d.F * 3;
+        default: return (int64_t)d.T * 18 * d.F;
+    }
+}
+int64_t array_count_device(const Dev &d, int id) {
+    switch (array_kind(id)) {
+        case 0: case 1: return (int64_t)d.V << d.tp_shift;
+        case 2: return ((int64_t)3 * d.F) << d.tp_shift;
+        default: return ((int64_t)18 * d.F) << d.tp_shift;
+    }
+}
+
+template <typename T>
+static int dev_alloc(Ctx *c, T **out, int64_t count, bool zero = true) {
+    void *p = nullptr;
+    const size_t bytes = sizeof(T) * (size_t)std::max<int64_t>(count, 1);
+    DOTS_HIP(hipMalloc(&p, bytes));
+    if (zero) DOTS_HIP(hipMemsetAsync(p, 0, bytes, c->stream));
+    if (c->n_allocs >= (int)(sizeof(c->allocs) / sizeof(c->allocs[0]))) {
+        set_error("allocation table full");
+        return DOTS_ERR_STATE;
+    }
+    c->allocs[c->n_allocs++] = p;
+    c->bytes += (int64_t)bytes;
+    *out = (T *)p;
+    return 0;
+}
+
+template <typename T>
+static int dev_upload(Ctx *c, const T **out, const T *host, int64_t count) {
+    T *p = nullptr;
+    int rc = dev_alloc(c, &p, count, false);
+    if (rc) return rc;
+    DOTS_HIP(hipMemcpyAsync(p, host, sizeof(T) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    DOTS_HIP(hipStreamSynchronize(c->stream));   // host buffers are borrowed for the call only
+    *out = p;
+    return 0;
+}
+
+static int build(Ctx *c, const dots_problem_desc *p) {
+    Dev &d = c->d;
+    d.T = p->n_time;
+    d.V = p->n_vertices;
+    d.F = p->n_triangles;
+    int tp = 8, sh = 3;
+    while (tp < d.T + 1) { tp <<= 1; ++sh; }
+    d.TP = tp;
+    d.tp_shift = sh;
+    if (tp > TILE_ELEMS) { set_error("n_time too large: T+1 must be <= 1024"); return DOTS_ERR_ARGUMENT; }
+    if (p->lap_solver == DOTS_LAP_MODAL_PCG && tp > BLOCK) { set_error("modal solver needs T+1 <= 256"); return DOTS_ERR_ARGUMENT; }
+    d.VT = d.FT = TILE_ELEMS / tp;
+    d.n_vtiles = (d.V + d.VT - 1) / d.VT;
+    d.n_ftiles = (3 * d.F + d.FT - 1) / d.FT;
+    d.h = 1.0 / d.T;
+    c->nnz = p->lap_nnz;
+    c->lap_solver = p->lap_solver;
+
+    const int V = d.V, F = d.F, nC = p->n_corners;
+    // host-side derived per-corner tables (constants of solver_socp.py:172-192 kept per corner, never broadcast)
+    std::vector<double> cD(nC), cgA((size_t)nC * 3), cArea(nC), kdiag(V, 0.0);
+    for (int v = 0; v < V; ++v) {
+        for (int j = p->corner_ptr[v]; j < p->corner_ptr[v + 1]; ++j) {
+            const int fk = p->corner_idx[j], f = fk / 3;
+            if (f < 0 || f >= F || p->triangles[fk] != v) { set_error("corner list inconsistent with triangles"); return DOTS_ERR_ARGUMENT; }
+            cD[j] = std::sqrt(p->area_tri[f] / p->mass_vert[v]);
+            cArea[j] = p->area_tri[f];
+            for (int cc = 0; cc < 3; ++cc) cgA[(size_t)j * 3 + cc] = p->hat_grad[(size_t)fk * 3 + cc] * p->area_tri[f];
+        }
+        bool has_diag = false;
+        for (int j = p->lap_rowptr[v]; j < p->lap_rowptr[v + 1]; ++j) {
+            if (p->lap_col[j] < 0 || p->lap_col[j] >= V) { set_error("lap_col out of range"); return DOTS_ERR_ARGUMENT; }
+            if (p->lap_col[j] == v) { kdiag[v] += p->lap_val[j]; has_diag = true; }
+        }
+        if (!has_diag || !(kdiag[v] > 0.0)) { set_error("surface stiffness matrix needs a positive diagonal"); return DOTS_ERR_ARGUMENT; }
+    }
+    for (int f = 0; f < F; ++f)
+        for (int k = 0; k < 3; ++k)
+            if (p->triangles[f * 3 + k] < 0 || p->triangles[f * 3 + k] >= V) { set_error("triangle index out of range"); return DOTS_ERR_ARGUMENT; }
+
+    int rc = 0;
+#define UP(field, src, n) if ((rc = dev_upload(c, &d.field, src, (int64_t)(n)))) return rc
+    UP(tri, p->triangles, F * 3);
+    UP(hat, p->hat_grad, F * 9);
+    UP(area_f, p->area_tri, F);
+    UP(mass_v, p->mass_vert, V);
+    UP(cptr, p->corner_ptr, V + 1);
+    UP(cidx, p->corner_idx, nC);
+    UP(c_D, cD.data(), nC);
+    UP(c_gA, cgA.data(), nC * 3);
+    UP(c_area, cArea.data(), nC);
+    UP(rowptr, p->lap_rowptr, V + 1);
+    UP(col, p->lap_col, p->lap_nnz);
+    UP(val, p->lap_val, p->lap_nnz);
+    UP(kdiag, kdiag.data(), V);
+    UP(mu0, p->mu0, V);
+    UP(mu1, p->mu1, V);
+    if (p->perm_vert) UP(perm_v, p->perm_vert, V);
+    if (p->perm_tri) UP(perm_f, p->perm_tri, F);
+    if (p->lap_solver == DOTS_LAP_MODAL_PCG) {
+        if (!p->time_modes || !p->time_eigs) { set_error("modal solver needs time_modes and time_eigs"); return DOTS_ERR_ARGUMENT; }
+        UP(Q, p->time_modes, (d.T + 1) * (d.T + 1));
+        std::vector<double> sig(tp, 0.0);
+        for (int i = 0; i <= d.T; ++i) sig[i] = p->time_eigs[i];
+        UP(sigma, sig.data(), tp);
+    }
+#undef UP
+
+    double **state[12] = {&d.phi, &d.A, &d.B, &d.lam, &d.zf, &d.zm, &d.ze, &d.mu, &d.E, &d.bf, &d.bm, &d.be};
+    for (int id = 0; id < DOTS_N_ARRAYS; ++id)
+        if ((rc = dev_alloc(c, state[id], array_count_device(d, id)))) return rc;
+    const int64_t nnode = (int64_t)V << sh;
+    double **cgv[7] = {&d.cg_b, &d.cg_r, &d.cg_z, &d.cg_p0, &d.cg_p1, &d.cg_Ap, &d.cg_x};
+    for (auto q : cgv)
+        if ((rc = dev_alloc(c, q, nnode))) return rc;
+    const int gv = xcd_grid(d.n_vtiles), gf = xcd_grid(d.n_ftiles);
+    const int64_t npart = std::max<int64_t>({(int64_t)MAX_SUMS * std::max(gv, gf) * 2, (int64_t)2 * (d.T + 1) * gv, 4096});
+    if ((rc = dev_alloc(c, &d.partials, npart))) return rc;
+    if ((rc = dev_alloc(c, &d.scal, CgScalOffsets::TOTAL))) return rc;
+    if ((rc = dev_alloc(c, &d.flags, FLAG_TOTAL))) return rc;
+    c->stage_count = array_count_device(d, DOTS_Z_MID);
+    if ((rc = dev_alloc(c, &c->stage, c->stage_count))) return rc;
+    DOTS_HIP(hipHostMalloc((void **)&c->h_pinned, sizeof(double) * CgScalOffsets::TOTAL, hipHostMallocDefault));
+    DOTS_HIP(hipHostMalloc((void **)&c->h_flags, sizeof(int) * FLAG_TOTAL, hipHostMallocDefault));
+
+    // KKT normalisation constants (solver_socp.py:303-313): means of the broadcast weight arrays
+    double sm = 0.0, sa = 0.0;
+    for (int v = 0; v < V; ++v) sm += p->mass_vert[v];
+    for (int f = 0; f < F; ++f) sa += p->area_tri[f];
+    const double mean_v = sm / V, mean_f = sa / F;
+    c->c_prim_q = 0.5 * (mean_v + mean_f);
+    c->c_prim_z = (mean_v + mean_f + mean_v) / 3.0;
+    c->c_dual_alpha = mean_v;
+    c->c_dual_beta = 0.5 * (mean_v + mean_f);
+    c->c_comp_rho = mean_v;
+    c->c_comp_m = mean_f;
+
+    dots_params &q = c->prm;
+    q.r = 1.0; q.scale_z = 1.0; q.const_d = 1.0; q.norm_d = std::sqrt(2.0 * sa);
+    double nb = 0.0;
+    for (int v = 0; v < V; ++v) nb += (p->mu0[v] * p->mu0[v] + p->mu1[v] * p->mu1[v]) / p->mass_vert[v];
+    q.norm_boundary = std::sqrt(nb / (d.T + 1));      // = r h sqrt(norm_square_center(boundary / mass)), :296
+    q.congestion = 0.0; q.tau = 1.9; q.eps = 0.0; q.prim_scale = 1.0; q.dual_scale = 1.0; q.boundary_scale = 1.0;
+    q.cg_tol = 1e-10; q.cg_max_iter = 20000;
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int check(dots_ctx *ctx) {
+    if (!ctx) { set_error("null context"); return DOTS_ERR_ARGUMENT; }
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
+    return 0;
+}
+
+static int run_iteration(Ctx *c, dots_step_stats *st) {
+    int rc;
+    DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
+    if ((rc = launch_rhs(c))) return rc;
+    DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
+    if ((rc = cg_solve(c, st))) return rc;
+    DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
+    if ((rc = launch_soc_projection(c))) return rc;
+    DOTS_HIP(hipEventRecord(c->ev[3], c->stream));
+    if ((rc = launch_q_lambda_mult(c))) return rc;
+    DOTS_HIP(hipEventRecord(c->ev[4], c->stream));
+    DOTS_HIP(hipEventSynchronize(c->ev[4]));
+    if (st) {
+        float t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); st->ms_rhs += t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); st->ms_laplacian += t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[3])); st->ms_soc += t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[3], c->ev[4])); st->ms_q_lambda_multiplier += t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[4])); st->ms_total += t;
+        st->alm_iterations += 1;
+    }
+    return 0;
+}
+
+}  // namespace dots
+
+using namespace dots;
+
+extern "C" {
+
+int dots_abi_version(void) { return DOTS_ABI_VERSION; }
+const char *dots_last_error(void) { return g_last_error.c_str(); }
+
+int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
+    if (!desc || !out) { set_error("null argument"); return DOTS_ERR_ARGUMENT; }
+    *out = nullptr;
+    if (desc->abi_version != DOTS_ABI_VERSION) { set_error("ABI version mismatch"); return DOTS_ERR_ARGUMENT; }
+    if (desc->n_time < 1 || desc->n_vertices < 3 || desc->n_triangles < 1 || desc->n_corners != 3 * desc->n_triangles) {
+        set_error("bad problem sizes");
+        return DOTS_ERR_ARGUMENT;
+    }
+    if (!desc->triangles || !desc->hat_grad || !desc->area_tri || !desc->mass_vert || !desc->corner_ptr || !desc->corner_idx ||
+        !desc->lap_rowptr || !desc->lap_col || !desc->lap_val || !desc->mu0 || !desc->mu1) {
+        set_error("null array in problem description");
+        return DOTS_ERR_ARGUMENT;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device"); return DOTS_ERR_NO_DEVICE; }
+    if (desc->device < 0 || desc->device >= ndev) { set_error("device ordinal out of range"); return DOTS_ERR_ARGUMENT; }
+    DOTS_HIP(hipSetDevice(desc->device));
+    dots_ctx *c = new dots_ctx();
+    c->device = desc->device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    for (auto &ev : c->ev) (void)hipEventCreate(&ev);
+    int rc = build(c, desc);
+    if (rc) { dots_destroy(c); return rc; }
+    *out = c;
+    return 0;
+}
+
+int dots_destroy(dots_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->cg_graph) (void)hipGraphExecDestroy(c->cg_graph);
+    for (int i = 0; i < c->n_allocs; ++i) (void)hipFree(c->allocs[i]);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_flags) (void)hipHostFree(c->h_flags);
+    for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int dots_set_params(dots_ctx *c, const dots_params *p) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (!p || !(p->r > 0) || !(p->scale_z > 0) || !(p->cg_tol > 0) || p->eps < 0 || !(p->boundary_scale > 0)) { set_error("bad parameters"); return DOTS_ERR_ARGUMENT; }
+    c->prm = *p;
+    return 0;
+}
+int dots_get_params(dots_ctx *c, dots_params *p) {
+    if (!c || !p) { set_error("null argument"); return DOTS_ERR_ARGUMENT; }
+    *p = c->prm;
+    return 0;
+}
+int dots_sync(dots_ctx *c) {
+    int rc = check(c);
+    if (rc) return rc;
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int64_t dots_array_count(dots_ctx *c, int id) {
+    if (!c || id < 0 || id >= DOTS_N_ARRAYS) return -1;
+    return array_count_host(c->d, id);
+}
+int64_t dots_device_bytes(dots_ctx *c) { return c ? c->bytes : -1; }
+
+int dots_upload(dots_ctx *c, int id, const double *host, int64_t count) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (id < 0 || id >= DOTS_N_ARRAYS || !host || count != array_count_host(c->d, id)) { set_error("upload: bad array id or element count"); return DOTS_ERR_ARGUMENT; }
+    DOTS_HIP(hipMemcpyAsync(c->stage, host, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_to_device_layout(c, id, c->stage))) return rc;
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int dots_download(dots_ctx *c, int id, double *host, int64_t count) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (id < 0 || id >= DOTS_N_ARRAYS || !host || count != array_count_host(c->d, id)) { set_error("download: bad array id or element count"); return DOTS_ERR_ARGUMENT; }
+    if ((rc = launch_from_device_layout(c, id, c->stage))) return rc;
+    DOTS_HIP(hipMemcpyAsync(host, c->stage, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (n_iters < 0) { set_error("n_iters < 0"); return DOTS_ERR_ARGUMENT; }
+    dots_step_stats local;
+    memset(&local, 0, sizeof local);
+    for (int i = 0; i < n_iters; ++i)
+        if ((rc = run_iteration(c, &local))) return rc;
+    if (stats) *stats = local;
+    return 0;
+}
+
+int dots_run_phase(dots_ctx *c, int phase, dots_step_stats *stats) {
+    int rc = check(c);
+    if (rc) return rc;
+    dots_step_stats local;
+    memset(&local, 0, sizeof local);
+    switch (phase) {
+        case DOTS_PHASE_LAPLACIAN:
+            if ((rc = launch_rhs(c))) return rc;
+            if ((rc = cg_solve(c, &local))) return rc;
+            break;
+        case DOTS_PHASE_SOC_PROJECTION: rc = launch_soc_projection(c); break;
+        case DOTS_PHASE_Q_LAMBDA_MULT: rc = launch_q_lambda_mult(c); break;
+        default: set_error("unknown phase"); return DOTS_ERR_ARGUMENT;
+    }
+    if (rc) return rc;
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    if (stats) *stats = local;
+    return 0;
+}
+
+int dots_kkt(dots_ctx *c, uint32_t mask, double *out) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (!out || (mask >> DOTS_N_KKT)) { set_error("kkt: bad mask or null output"); return DOTS_ERR_ARGUMENT; }
+    if (!mask) return 0;
+    return kkt_evaluate(c, mask, out);
+}
+int dots_objective(dots_ctx *c, double *out) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (!out) { set_error("null output"); return DOTS_ERR_ARGUMENT; }
+    return objective_evaluate(c, out);
+}
+
+int dots_adjust_penalty(dots_ctx *c, double factor) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (!(factor > 0)) { set_error("factor must be positive"); return DOTS_ERR_ARGUMENT; }
+    return launch_adjust_penalty(c, factor);
+}
+int dots_scale_z(dots_ctx *c, double z_mul, double beta_mul, double sz_new) {
+    int rc = check(c);
+    if (rc) return rc;
+    return launch_scale_z(c, z_mul, beta_mul, sz_new);
+}
+int dots_scale_arrays(dots_ctx *c, uint32_t mask, double factor) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (mask >> DOTS_N_ARRAYS) { set_error("bad array mask"); return DOTS_ERR_ARGUMENT; }
+    for (int id = 0; id < DOTS_N_ARRAYS; ++id)
+        if ((mask >> id) & 1u)
+            if ((rc = launch_scale_array(c, id, factor))) return rc;
+    return 0;
+}
+int dots_norm_square(dots_ctx *c, int id, int part, double *out) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (id < 0 || id >= DOTS_N_ARRAYS || !out || part < 0 || part > 2) { set_error("norm_square: bad argument"); return DOTS_ERR_ARGUMENT; }
+    return norm_square(c, id, part, out);
+}
+
+int dots_apply_operator(dots_ctx *c, int op, double scale, const double *in, int64_t n_in, double *out, int64_t n_out) {
+    int rc = check(c);
+    if (rc) return rc;
+    // (input array class, output array class) per operator, expressed through state arrays of the same shape
+    int in_id, out_id;
+    switch (op) {
+        case DOTS_OP_GRAD_TIME: in_id = DOTS_PHI; out_id = DOTS_A; break;
+        case DOTS_OP_DIV_TIME: case DOTS_OP_TIME_AVG_ADJOINT: in_id = DOTS_A; out_id = DOTS_PHI; break;
+        case DOTS_OP_GRAD_SPACE: in_id = DOTS_PHI; out_id = DOTS_B; break;
+        case DOTS_OP_DIV_SPACE: in_id = DOTS_B; out_id = DOTS_PHI; break;
+        case DOTS_OP_DECOUPLE: in_id = DOTS_B; out_id = DOTS_Z_MID; break;
+        case DOTS_OP_DECOUPLE_ADJOINT: in_id = DOTS_Z_MID; out_id = DOTS_B; break;
+        case DOTS_OP_LAPLACIAN_APPLY: in_id = DOTS_PHI; out_id = DOTS_PHI; break;
+        default: set_error("unknown operator"); return DOTS_ERR_ARGUMENT;
+    }
+    if (!in || !out || n_in != array_count_host(c->d, in_id) || n_out != array_count_host(c->d, out_id)) {
+        set_error("apply_operator: bad element counts");
+        return DOTS_ERR_ARGUMENT;
+    }
+    // scratch: device-layout input and output live in two temporary buffers
+    double *din = nullptr, *dout = nullptr;
+    const int64_t cin = array_count_device(c->d, in_id), cout = array_count_device(c->d, out_id);
+    DOTS_HIP(hipMalloc((void **)&din, sizeof(double) * (size_t)cin));
+    DOTS_HIP(hipMalloc((void **)&dout, sizeof(double) * (size_t)cout));
+    DOTS_HIP(hipMemsetAsync(dout, 0, sizeof(double) * (size_t)cout, c->stream));
+    DOTS_HIP(hipMemcpyAsync(c->stage, in, sizeof(double) * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
+    // reuse the layout kernels by temporarily pointing the state slot at the scratch buffers
+    Ctx tmp = *c;
+    double **slot_in[12] = {&tmp.d.phi, &tmp.d.A, &tmp.d.B, &tmp.d.lam, &tmp.d.zf, &tmp.d.zm, &tmp.d.ze, &tmp.d.mu, &tmp.d.E, &tmp.d.bf, &tmp.d.bm, &tmp.d.be};
+    *slot_in[in_id] = din;
+    rc = launch_to_device_layout(&tmp, in_id, c->stage);
+    if (!rc) {
+        if (op == DOTS_OP_LAPLACIAN_APPLY) rc = cg_apply_operator(c, din, dout);
+        else rc = launch_operator(c, op, scale, din, dout);
+    }
+    if (!rc) {
+        Ctx tmp2 = *c;
+        double **slot_out[12] = {&tmp2.d.phi, &tmp2.d.A, &tmp2.d.B, &tmp2.d.lam, &tmp2.d.zf, &tmp2.d.zm, &tmp2.d.ze, &tmp2.d.mu, &tmp2.d.E, &tmp2.d.bf, &tmp2.d.bm, &tmp2.d.be};
+        *slot_out[out_id] = dout;
+        rc = launch_from_device_layout(&tmp2, out_id, c->stage);
+    }
+    hipError_t e1 = hipMemcpyAsync(out, c->stage, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    if (rc) return rc;
+    DOTS_HIP(e1);
+    DOTS_HIP(e2);
+    return 0;
+}
+
+int dots_bench_kernel(dots_ctx *c, int which, int reps, double *ms, double *bytes) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (reps < 1 || !ms || !bytes) { set_error("bench: bad argument"); return DOTS_ERR_ARGUMENT; }
+    return cg_bench(c, which, reps, ms, bytes);
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// Internal declarations shared by the HIP translation units of libdotsocp_hip.so (gfx950 only).
+//
+// Device data layout ("time-fastest"): every spatial gather of the path -- a vertex reading its
+// neighbours / corners, a triangle reading its three vertices -- touches one contiguous row of
+// TP doubles (TP = time pitch, power of two >= T+1), so all HBM reads coalesce:
+//     node / interval arrays   x[v][t]                 idxV(v,t)       = v*TP + t
+//     triangle arrays          B[f][c][t]              idxF(f,c,t)     = (f*3+c)*TP + t
+//     corner arrays            z_mid[f][k][s][c][t]    idxM(f,k,s,c,t) = ((((f*3+k)*2+s)*3+c)*TP + t
+// Interval arrays use t in [0,T), node arrays t in [0,T]; padding columns stay zero.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/dots_socp_hip.h"
+
+namespace dots {
+
+constexpr int BLOCK = 256;           // threads per workgroup = 4 wave64
+constexpr int TILE_ELEMS = 1024;     // (vertex,time) elements per workgroup tile
+constexpr int LDS_NNZ_CAP = 1536;    // CSR entries of one row block staged in LDS (18 KB)
+constexpr int MAX_SUMS = 24;         // reduction slots per kernel
+constexpr double INV_SQRT3 = 0.57735026918962576451;
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define DOTS_HIP(call)                                                        \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) return ::dots::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// Everything a kernel needs, passed by value.
+struct Dev {
+    int T, V, F, TP, tp_shift;
+    int VT;          // vertices per tile = TILE_ELEMS / TP
+    int n_vtiles;    // ceil(V / VT)
+    int FT;          // (triangle,component) rows per tile = TILE_ELEMS / TP
+    int n_ftiles;    // ceil(3F / FT)
+    double h;        // 1 / T
+    // mesh constants
+    const int *tri;          // [F][3]
+    const double *hat;       // [F][3][3]
+    const double *area_f;    // [F]
+    const double *mass_v;    // [V]
+    const int *cptr;         // [V+1]
+    const int *cidx;         // [3F]  f*3+k
+    const double *c_D;       // [3F]  sqrt(area_f / mass_v) per corner-list entry
+    const double *c_gA;      // [3F][3] hat gradient * area_f per corner-list entry
+    const double *c_area;    // [3F]  area_f per corner-list entry
+    const int *rowptr;       // [V+1]
+    const int *col;          // [nnz]
+    const double *val;       // [nnz]
+    const double *kdiag;     // [V] diagonal of K
+    const double *mu0, *mu1; // [V]
+    const int *perm_v, *perm_f;
+    const double *Q;         // [(T+1)^2] or null
+    const double *sigma;     // [T+1] or null
+    // state
+    double *phi, *A, *B, *lam, *zf, *zm, *ze, *mu, *E, *bf, *bm, *be;
+    // PCG workspace (node layout)
+    double *cg_b, *cg_r, *cg_z, *cg_p0, *cg_p1, *cg_Ap, *cg_x;
+    double *partials;        // [MAX_SUMS or NC][n partial blocks]
+    double *scal;            // device scalars, see CgScal / sums
+    int *flags;
+};
+
+// Layout of the device scalar block used by the PCG (all arrays have NC entries, NC <= 256).
+struct CgScalOffsets {
+    static constexpr int NCMAX = 256;
+    static constexpr int RZ = 0;
+    static constexpr int PAP = NCMAX;
+    static constexpr int ALPHA = 2 * NCMAX;
+    static constexpr int BETA = 3 * NCMAX;
+    static constexpr int BREF = 4 * NCMAX;
+    static constexpr int BMEAN = 5 * NCMAX;
+    static constexpr int SUMS = 6 * NCMAX;     // MAX_SUMS reduction results for KKT / norms
+    static constexpr int TOTAL = 6 * NCMAX + 64;
+};
+// flags: [0..NCMAX) done per column, [NCMAX] iteration counter
+constexpr int FLAG_ITERS = CgScalOffsets::NCMAX;
+constexpr int FLAG_TOTAL = CgScalOffsets::NCMAX + 8;
+
+struct Ctx;
+
+// ---- launch wrappers implemented in the kernel files (all asynchronous on ctx stream) ----
+int launch_soc_projection(Ctx *c);
+int launch_rhs(Ctx *c);
+int launch_q_lambda_mult(Ctx *c);
+int launch_adjust_penalty(Ctx *c, double factor);
+int launch_scale_z(Ctx *c, double z_mul, double beta_mul, double sz_new);
+int launch_scale_array(Ctx *c, int array_id, double factor);
+int launch_to_device_layout(Ctx *c, int array_id, const double *staged);
+int launch_from_device_layout(Ctx *c, int array_id, double *staged);
+int launch_operator(Ctx *c, int op, double scale, const double *in_staged, double *out_staged);
+int cg_solve(Ctx *c, dots_step_stats *stats);
+int cg_apply_operator(Ctx *c, const double *x_node, double *y_node);  // y = K x in node layout
+int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes);
+int kkt_evaluate(Ctx *c, uint32_t mask, double *out);
+int objective_evaluate(Ctx *c, double *out);
+int norm_square(Ctx *c, int array_id, int part, double *out);
+int reduce_partials(Ctx *c, const double *partials, int n_slots, int n_blocks, int first_slot);  // -> scal[SUMS+first_slot+slot]
+
+struct Ctx {
+    Dev d{};
+    dots_params prm{};
+    int device = 0;
+    int lap_solver = 0;
+    int nnz = 0;
+    int64_t bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8]{};
+    double *stage = nullptr;      // device staging buffer (largest state array)
+    int64_t stage_count = 0;
+    double *h_pinned = nullptr;   // pinned host scalars
+    int *h_flags = nullptr;
+    int n_partial_blocks = 0;
+    int last_cg_iters = 0;
+    // constants of the KKT normalisation (solver_socp.py:303-313)
+    double c_prim_q = 0, c_prim_z = 0, c_dual_alpha = 0, c_dual_beta = 0, c_comp_rho = 0, c_comp_m = 0;
+    void *allocs[64]{};
+    int n_allocs = 0;
+    // hipGraph cache of the PCG iteration body
+    hipGraphExec_t cg_graph = nullptr;
+    int cg_graph_iters = 0;
+    double cg_graph_eps = -1.0;
+    double cg_graph_tol = -1.0;
+    double *arr(int id) {
+        double *t[12] = {d.phi, d.A, d.B, d.lam, d.zf, d.zm, d.ze, d.mu, d.E, d.bf, d.bm, d.be};
+        return t[id];
+    }
+};
+
+int64_t array_count_host(const Dev &d, int array_id);    // elements in the reference layout
+int64_t array_count_device(const Dev &d, int array_id);  // elements in the device layout
+int array_kind(int array_id);  // 0 node (T+1,V), 1 interval (T,V), 2 triangle (T+1,F,3), 3 corner (T,2,3,F,3)
+
+#ifdef __HIPCC__
+// ---- device helpers ---------------------------------------------------------------------
+__device__ __forceinline__ int idxV(const Dev &d, int v, int t) { return (v << d.tp_shift) + t; }
+__device__ __forceinline__ int64_t idxF(const Dev &d, int f, int c, int t) { return ((int64_t)(f * 3 + c) << d.tp_shift) + t; }
+__device__ __forceinline__ int64_t idxM(const Dev &d, int fk, int s, int c, int t) {
+    return ((int64_t)((fk * 2 + s) * 3 + c) << d.tp_shift) + t;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give every XCD one
+// contiguous range of tiles so that neighbouring tiles, which gather the same rows, share an L2.
+__device__ __forceinline__ int xcd_tile(int b, int n_tiles) {
+    int per = (n_tiles + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+inline int xcd_grid(int n_tiles) { return ((n_tiles + 7) / 8) * 8; }
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;
+}
+
+// Sum N per-thread values over the workgroup; thread 0 gets the totals.  Fixed order -> deterministic.
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double *lds /* [N*4] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = wave_sum(v[i]);
+        if (lane == 0) lds[i * 4 + w] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = (lds[i * 4] + lds[i * 4 + 1]) + (lds[i * 4 + 2] + lds[i * 4 + 3]);
+    }
+}
+#endif
+
+}  // namespace dots

@@ -1,0 +1,416 @@
+// ALM element-wise / gather kernels for gfx950: second-order-cone projection, right-hand side
+// of the phi step, the fused (q, lambda_c) + multiplier update, scaling tools, layout conversion.
+// All HBM-bound fp64; one thread per (row, time) element, rows = vertices or (triangle, xyz).
+#include "dots_dev.h"
+
+namespace dots {
+
+// ------------------------------------------------------------------------------------------
+// Step 1-2  second-order-cone projection      (reference: solver_socp.py:988-1042)
+//
+// Cone of (t, v):  z_fst >= || ( z_end, D[k,f] * z_mid[t, s, k, f, c]  over the corners (f,k) of v ) ||.
+// The reference does this with two 0/1 incidence SpMVs and >= 9 passes over 18*T*F-sized arrays;
+// here one thread owns (v, t): it walks the vertex's corner list once to accumulate the squared
+// norm, forms lambda, and walks it again to write z_mid of its own corners (no atomics: every
+// corner belongs to exactly one vertex).  beta_mid is read from HBM once, the second walk hits L2.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, double cd) {
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    if (tile >= d.n_vtiles) return;
+    const int v0 = tile * d.VT;
+    const double sB = sz * INV_SQRT3;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (v >= d.V || t >= d.T) continue;
+        const int iv = idxV(d, v, t);
+        const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
+        double acc = 0.0;
+        for (int j = j0; j < j1; ++j) {
+            const int fk = d.cidx[j];
+            const int f = fk / 3;
+            const double D = d.c_D[j];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double w = D * (sB * d.B[idxF(d, f, c, t + s)] - d.bm[idxM(d, fk, s, c, t)]);
+                    acc += w * w;
+                }
+        }
+        const double a = d.A[iv];
+        const double w_fst = cd - sz * a - d.bf[iv];
+        const double w_end = cd + sz * a - d.be[iv];
+        const double nrm = sqrt(acc + w_end * w_end);
+        double lam = 0.5 * (1.0 + w_fst / nrm);          // 0/0 -> NaN when the pre-image is 0, as in the reference (:1018)
+        if (lam == lam) lam = fmin(fmax(lam, 0.0), 1.0);  // np.clip keeps NaN; fmin/fmax would drop it
+        d.zf[iv] = (lam >= 1.0) ? w_fst : lam * nrm;
+        d.ze[iv] = lam * w_end;
+        for (int j = j0; j < j1; ++j) {
+            const int fk = d.cidx[j];
+            const int f = fk / 3;
+            const double D = d.c_D[j];
+            const double lt = lam / D;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double w = D * (sB * d.B[idxF(d, f, c, t + s)] - d.bm[idxM(d, fk, s, c, t)]);
+                    d.zm[idxM(d, fk, s, c, t)] = lt * w;
+                }
+        }
+    }
+}
+
+int launch_soc_projection(Ctx *c) {
+    hipLaunchKernelGGL(k_soc_projection, dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, c->prm.scale_z,
+                       c->prm.const_d);
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Step 1-1 right-hand side                    (reference: solver_socp.py:976-986, :886-921)
+//   rhs = div_t((A + lambda_c - mu) * mass) + div_x((B - E) * area) - boundary - eps * mass * phi
+// The PCG solves K phi = b with K = -Laplacian (SPD-semidefinite), so b = -rhs is stored.
+// div_x is a gather over the vertex's corner list (no scatter, no atomics).  Each workgroup also
+// emits the partial sum of b (mean removal for the singular eps = 0 operator).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps) {
+    __shared__ double lds[4];
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    double part[1] = {0.0};
+    if (tile < d.n_vtiles) {
+        const int v0 = tile * d.VT;
+        const double ih = 1.0 / d.h;
+        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+            const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
+            if (v >= d.V || t > d.T) continue;
+            const int iv = idxV(d, v, t);
+            const double m = d.mass_v[v];
+            double xt = 0.0, xm = 0.0;
+            if (t < d.T) xt = (d.A[iv] + d.lam[iv] - d.mu[iv]) * m;
+            if (t > 0) xm = (d.A[iv - 1] + d.lam[iv - 1] - d.mu[iv - 1]) * m;
+            double rhs = (xt - xm) * ih;
+            double ds = 0.0;
+            for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+                const int f = d.cidx[j] / 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int64_t i = idxF(d, f, c, t);
+                    ds += d.c_gA[j * 3 + c] * (d.B[i] - d.E[i]);
+                }
+            }
+            rhs -= ds;
+            if (t == 0) rhs += d.mu0[v] / (r * d.h);
+            if (t == d.T) rhs -= d.mu1[v] / (r * d.h);
+            rhs -= eps * m * d.phi[iv];
+            const double b = -rhs;
+            d.cg_b[iv] = b;
+            part[0] += b;
+        }
+    }
+    block_sum<1>(part, lds);
+    if (threadIdx.x == 0) d.partials[blockIdx.x] = part[0];
+}
+
+int launch_rhs(Ctx *c) {
+    const int g = xcd_grid(c->d.n_vtiles);
+    hipLaunchKernelGGL(k_rhs, dim3(g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps);
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Steps 2 + 3 fused                            (reference: solver_socp.py:709-722, :1044-1065)
+// Vertex part, thread (v, t < T):
+//     dphi = (phi[t+1] - phi[t]) / h
+//     A = (dphi + mu)/a2 + (a1/a2)(z_end + beta_end - z_fst - beta_fst);  lambda_c = cr/(1+cr) (dphi + mu - A)
+//     mu += tau (dphi - A - lambda_c);  beta_fst += tau (z_fst + sz A - d);  beta_end += tau (z_end - sz A - d)
+// Triangle part, thread (f, c, t <= T):
+//     gx = sum_k hat[f][k][c] phi[tri[f][k]][t]                       (grad_space, 3 coalesced row gathers)
+//     B  = (gx + E + sz/sqrt3 * (sum_k (z_mid+beta_mid)[t][s=0] + sum_k (z_mid+beta_mid)[t-1][s=1])) / diag_b[t]
+//     E += tau (gx - B)
+//     beta_mid[t][0][k] += tau (z_mid - sz/sqrt3 B[t]);  beta_mid[t-1][1][k] += tau (z_mid - sz/sqrt3 B[t])
+// Every beta_mid entry is attached to the node whose B it is compared with, so the thread that
+// computes B[t] updates them without any exchange: z_mid and beta_mid are read once, beta_mid written once.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_vertex(Dev d, double sz, double cd, double cr, double tau) {
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    if (tile >= d.n_vtiles) return;
+    const int v0 = tile * d.VT;
+    const double a1 = sz * (1.0 + cr);
+    const double a2 = 1.0 + 2.0 * sz * a1;
+    const double ia2 = 1.0 / a2, a12 = a1 / a2, cl = cr / (1.0 + cr), ih = 1.0 / d.h;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (v >= d.V || t >= d.T) continue;
+        const int iv = idxV(d, v, t);
+        const double dphi = (d.phi[iv + 1] - d.phi[iv]) * ih;
+        const double mu = d.mu[iv], zf = d.zf[iv], ze = d.ze[iv], bf = d.bf[iv], be = d.be[iv];
+        const double memo = dphi + mu;
+        const double a = ia2 * memo + a12 * (ze + be - zf - bf);
+        const double lc = cl * (memo - a);
+        d.A[iv] = a;
+        d.lam[iv] = lc;
+        d.mu[iv] = mu + tau * (dphi - a - lc);
+        d.bf[iv] = bf + tau * (zf + sz * a - cd);
+        d.be[iv] = be + tau * (ze - sz * a - cd);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double sz, double tau) {
+    const int tile = xcd_tile(blockIdx.x, d.n_ftiles);
+    if (tile >= d.n_ftiles) return;
+    const int row0 = tile * d.FT;
+    const double sB = sz * INV_SQRT3;
+    const double diag_in = 1.0 + 2.0 * sz * sz, diag_bd = 1.0 + sz * sz;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int row = row0 + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (row >= 3 * d.F || t > d.T) continue;
+        const int f = row / 3, c = row - 3 * f;
+        double gx = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gx += d.hat[(f * 3 + k) * 3 + c] * d.phi[idxV(d, d.tri[f * 3 + k], t)];
+        double z0[3], b0[3], z1[3], b1[3];
+        double S = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            z0[k] = b0[k] = z1[k] = b1[k] = 0.0;
+            if (t < d.T) {
+                const int64_t i = idxM(d, f * 3 + k, 0, c, t);
+                z0[k] = d.zm[i];
+                b0[k] = d.bm[i];
+            }
+            if (t > 0) {
+                const int64_t i = idxM(d, f * 3 + k, 1, c, t - 1);
+                z1[k] = d.zm[i];
+                b1[k] = d.bm[i];
+            }
+            S += (z0[k] + b0[k]) + (z1[k] + b1[k]);
+        }
+        const int64_t ie = idxF(d, f, c, t);
+        const double Eo = d.E[ie];
+        const double Bn = (gx + Eo + sB * S) / ((t == 0 || t == d.T) ? diag_bd : diag_in);
+        d.B[ie] = Bn;
+        d.E[ie] = Eo + tau * (gx - Bn);
+        const double sBn = sB * Bn;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (t < d.T) d.bm[idxM(d, f * 3 + k, 0, c, t)] = b0[k] + tau * (z0[k] - sBn);
+            if (t > 0) d.bm[idxM(d, f * 3 + k, 1, c, t - 1)] = b1[k] + tau * (z1[k] - sBn);
+        }
+    }
+}
+
+int launch_q_lambda_mult(Ctx *c) {
+    const dots_params &p = c->prm;
+    hipLaunchKernelGGL(k_q_lambda_mult_vertex, dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, p.scale_z,
+                       p.const_d, p.congestion * p.r, p.tau);
+    hipLaunchKernelGGL(k_q_lambda_mult_triangle, dim3(xcd_grid(c->d.n_ftiles)), dim3(BLOCK), 0, c->stream, c->d, p.scale_z,
+                       p.tau);
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// scaling tools                                (reference: solver_socp.py:367-395)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_scale(double *x, int64_t n, double f) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) x[i] *= f;
+}
+__global__ __launch_bounds__(BLOCK) void k_divide(double *x, int64_t n, double f) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) x[i] /= f;
+}
+
+static int grid_for(int64_t n) {
+    int64_t g = (n + BLOCK - 1) / BLOCK;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+int launch_scale_array(Ctx *c, int id, double f) {
+    const int64_t n = array_count_device(c->d, id);
+    hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, c->arr(id), n, f);
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_adjust_penalty(Ctx *c, double factor) {  // :367-371 (the boundary term is rebuilt from r in k_rhs)
+    const int ids[5] = {DOTS_MU, DOTS_E, DOTS_BETA_FST, DOTS_BETA_MID, DOTS_BETA_END};
+    for (int id : ids) {
+        const int64_t n = array_count_device(c->d, id);
+        hipLaunchKernelGGL(k_divide, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, c->arr(id), n, factor);
+    }
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
+// mu = sz (beta_fst - beta_end);  E = - L^T(beta_mid; sz)          (:386-388)
+__global__ __launch_bounds__(BLOCK) void k_rebuild_mu(Dev d, double sz) {
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    if (tile >= d.n_vtiles) return;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (v >= d.V || t >= d.T) continue;
+        const int iv = idxV(d, v, t);
+        d.mu[iv] = sz * (d.bf[iv] - d.be[iv]);
+    }
+}
+__device__ __forceinline__ double dec_adjoint_at(const Dev &d, const double *x, int f, int c, int t) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (t < d.T) s0 += x[idxM(d, f * 3 + k, 0, c, t)];
+        if (t > 0) s1 += x[idxM(d, f * 3 + k, 1, c, t - 1)];
+    }
+    return s0 + s1;
+}
+__global__ __launch_bounds__(BLOCK) void k_rebuild_E(Dev d, double sz) {
+    const int tile = xcd_tile(blockIdx.x, d.n_ftiles);
+    if (tile >= d.n_ftiles) return;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (row >= 3 * d.F || t > d.T) continue;
+        const int f = row / 3, c = row - 3 * f;
+        d.E[idxF(d, f, c, t)] = -(sz * INV_SQRT3) * dec_adjoint_at(d, d.bm, f, c, t);
+    }
+}
+
+int launch_scale_z(Ctx *c, double z_mul, double beta_mul, double sz_new) {
+    const int zs[3] = {DOTS_Z_FST, DOTS_Z_MID, DOTS_Z_END}, bs[3] = {DOTS_BETA_FST, DOTS_BETA_MID, DOTS_BETA_END};
+    for (int id : zs) launch_scale_array(c, id, z_mul);
+    for (int id : bs) launch_scale_array(c, id, beta_mul);
+    hipLaunchKernelGGL(k_rebuild_mu, dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, sz_new);
+    hipLaunchKernelGGL(k_rebuild_E, dim3(xcd_grid(c->d.n_ftiles)), dim3(BLOCK), 0, c->stream, c->d, sz_new);
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout conversion: reference layout (time-major) <-> device layout (time-fastest, permuted)
+// ------------------------------------------------------------------------------------------
+template <bool TO_DEV>
+__global__ __launch_bounds__(BLOCK) void k_convert(Dev d, int kind, double *dev, double *host) {
+    // one thread per device element (t fastest -> device side coalesced; host side strided, staging only)
+    const int nt = (kind == 0 || kind == 2) ? d.T + 1 : d.T;
+    const int64_t rows = (kind <= 1) ? d.V : (kind == 2 ? (int64_t)3 * d.F : (int64_t)18 * d.F);
+    const int64_t n = rows << d.tp_shift;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const int t = (int)(i & (d.TP - 1));
+        const int64_t row = i >> d.tp_shift;
+        if (t >= nt) {
+            if (TO_DEV) dev[i] = 0.0;
+            continue;
+        }
+        int64_t h;
+        if (kind <= 1) {
+            const int v = d.perm_v ? d.perm_v[row] : (int)row;
+            h = (int64_t)t * d.V + v;
+        } else if (kind == 2) {
+            const int f = (int)(row / 3), c = (int)(row - 3 * (row / 3));
+            const int fo = d.perm_f ? d.perm_f[f] : f;
+            h = ((int64_t)t * d.F + fo) * 3 + c;
+        } else {  // row = ((f*3+k)*2+s)*3+c  ->  host [t][s][k][f][c]
+            const int c = (int)(row % 3);
+            const int s = (int)((row / 3) % 2);
+            const int k = (int)((row / 6) % 3);
+            const int f = (int)(row / 18);
+            const int fo = d.perm_f ? d.perm_f[f] : f;
+            h = ((((int64_t)t * 2 + s) * 3 + k) * d.F + fo) * 3 + c;
+        }
+        if (TO_DEV) dev[i] = host[h];
+        else host[h] = dev[i];
+    }
+}
+
+int launch_to_device_layout(Ctx *c, int id, const double *staged) {
+    const int64_t n = array_count_device(c->d, id);
+    hipLaunchKernelGGL(k_convert<true>, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, c->d, array_kind(id), c->arr(id),
+                       const_cast<double *>(staged));
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+int launch_from_device_layout(Ctx *c, int id, double *staged) {
+    const int64_t n = array_count_device(c->d, id);
+    hipLaunchKernelGGL(k_convert<false>, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, c->d, array_kind(id), c->arr(id), staged);
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// standalone operators (rows a4-a6): same index arithmetic as the fused kernels, exposed so each
+// reference function has a one-to-one parity test.  in/out are device-layout scratch arrays.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_op_vertex(Dev d, int op, const double *x, double *y) {
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    if (tile >= d.n_vtiles) return;
+    const double ih = 1.0 / d.h;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (v >= d.V) continue;
+        const int iv = idxV(d, v, t);
+        if (op == DOTS_OP_GRAD_TIME) {
+            y[iv] = (t < d.T) ? (x[iv + 1] - x[iv]) * ih : 0.0;
+        } else if (op == DOTS_OP_DIV_TIME || op == DOTS_OP_TIME_AVG_ADJOINT) {
+            if (t > d.T) { y[iv] = 0.0; continue; }
+            const double a = (t < d.T) ? x[iv] : 0.0, b = (t > 0) ? x[iv - 1] : 0.0;
+            y[iv] = (op == DOTS_OP_DIV_TIME) ? (a - b) * ih : 0.5 * (a + b);
+        } else if (op == DOTS_OP_DIV_SPACE) {
+            if (t > d.T) { y[iv] = 0.0; continue; }
+            double ds = 0.0;
+            for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+                const int fk = d.cidx[j], f = fk / 3, k = fk - 3 * f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ds += d.hat[(f * 3 + k) * 3 + c] * x[idxF(d, f, c, t)];
+            }
+            y[iv] = -ds;
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_op_triangle(Dev d, int op, double scale, const double *x, double *y) {
+    const int tile = xcd_tile(blockIdx.x, d.n_ftiles);
+    if (tile >= d.n_ftiles) return;
+    const double sB = scale * INV_SQRT3;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (row >= 3 * d.F || t > d.T) continue;
+        const int f = row / 3, c = row - 3 * f;
+        if (op == DOTS_OP_GRAD_SPACE) {
+            double gx = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gx += d.hat[(f * 3 + k) * 3 + c] * x[idxV(d, d.tri[f * 3 + k], t)];
+            y[idxF(d, f, c, t)] = gx;
+        } else if (op == DOTS_OP_DECOUPLE) {
+            const double b = sB * x[idxF(d, f, c, t)];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (t < d.T) y[idxM(d, f * 3 + k, 0, c, t)] = b;
+                if (t > 0) y[idxM(d, f * 3 + k, 1, c, t - 1)] = b;
+            }
+        } else if (op == DOTS_OP_DECOUPLE_ADJOINT) {
+            y[idxF(d, f, c, t)] = sB * dec_adjoint_at(d, x, f, c, t);
+        }
+    }
+}
+
+int launch_operator(Ctx *c, int op, double scale, const double *in, double *out) {
+    switch (op) {
+        case DOTS_OP_GRAD_TIME:
+        case DOTS_OP_DIV_TIME:
+        case DOTS_OP_TIME_AVG_ADJOINT:
+        case DOTS_OP_DIV_SPACE:
+            hipLaunchKernelGGL(k_op_vertex, dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, op, in, out);
+            break;
+        case DOTS_OP_GRAD_SPACE:
+        case DOTS_OP_DECOUPLE:
+        case DOTS_OP_DECOUPLE_ADJOINT:
+            hipLaunchKernelGGL(k_op_triangle, dim3(xcd_grid(c->d.n_ftiles)), dim3(BLOCK), 0, c->stream, c->d, op, scale, in, out);
+            break;
+        default:
+            set_error("unknown operator");
+            return DOTS_ERR_ARGUMENT;
+    }
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dots

@@ -1,0 +1,387 @@
+// KKT residuals, objective and weighted norms (reference: solver_socp.py:417-559, :875-878).
+//
+// The reference evaluates each residual with several numpy passes and temporaries the size of the
+// state.  Here two kernels (one vertex-major, one triangle-major) read the state once and emit all
+// weighted sums a requested set of conditions needs; a small kernel adds the per-workgroup partials
+// in a fixed order (wave64 __shfl reductions inside the workgroup, no atomics -> deterministic) and
+// the ~20 scalars are combined on the host side of the C ABI exactly as the reference's closures do.
+#include "dots_dev.h"
+
+#include <cmath>
+
+namespace dots {
+
+using S = CgScalOffsets;
+
+enum {
+    V_DPHI2 = 0, V_A2, V_LAM2, V_RESMU2, V_RFST2, V_REND2, V_MU2, V_AUX1_2, V_MUAUX1_2,
+    V_COMP_AUX2, V_COMP_RES2, V_CONG_RES2, V_DUALAUX2, N_VSUMS,
+    F_DX2 = N_VSUMS, F_B2, F_RESE2, F_E2, F_AUX2_2, F_EAUX2_2, F_AUX5_2, F_AUX5M_2, F_RMID2, N_SUMS
+};
+constexpr int N_FSUMS = N_SUMS - N_VSUMS;
+static_assert(N_SUMS <= MAX_SUMS, "too many reduction slots");
+
+struct KktArgs {
+    uint32_t mask;
+    double r, sz, cd, cong, ps, ds, bs;   // penalty, scale_factor_z, constant_d, congestion, prim/dual/boundary scale
+};
+
+__global__ __launch_bounds__(BLOCK) void k_kkt_vertex(Dev d, KktArgs a) {
+    __shared__ double lds[N_VSUMS * 4];
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    double s[N_VSUMS];
+#pragma unroll
+    for (int i = 0; i < N_VSUMS; ++i) s[i] = 0.0;
+    const bool c0 = a.mask & 1u, c1 = a.mask & 2u, c2 = a.mask & 4u, c3 = a.mask & 8u, c4 = a.mask & 16u, c6 = a.mask & 64u;
+    if (tile < d.n_vtiles) {
+        const double ih = 1.0 / d.h, rho_s = a.ds * a.r;
+        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+            const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
+            if (v >= d.V || t > d.T) continue;
+            const int iv = idxV(d, v, t);
+            const double m = d.mass_v[v];
+            if (t < d.T) {
+                const double A = d.A[iv], mu = d.mu[iv], lc = d.lam[iv];
+                if (c0) {   // Prim(phi, q): solver_socp.py:433-450, residuals of :592-593
+                    const double dphi = (d.phi[iv + 1] - d.phi[iv]) * ih;
+                    const double rm = dphi - A - lc;
+                    s[V_DPHI2] += dphi * dphi * m;
+                    s[V_A2] += A * A * m;
+                    s[V_RESMU2] += rm * rm * m;
+                }
+                if (c0 || c6) s[V_LAM2] += lc * lc * m;
+                if (c1) {   // Prim(q, z): :452-464 with :598-600
+                    const double rf = d.zf[iv] + a.sz * A - a.cd, re = d.ze[iv] - a.sz * A - a.cd;
+                    s[V_RFST2] += rf * rf * m;
+                    s[V_REND2] += re * re * m;
+                }
+                if (c3 || c4 || c6) s[V_MU2] += mu * mu * m;
+                if (c3) {   // Dual(beta): :484-503
+                    const double a1 = a.sz * (d.be[iv] - d.bf[iv]);
+                    s[V_AUX1_2] += a1 * a1 * m;
+                    s[V_MUAUX1_2] += (mu + a1) * (mu + a1) * m;
+                }
+                if (c4) {   // Comp(rho, f(q)): :505-526 with :615-619
+                    double q = 0.0;
+                    for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+                        const int f = d.cidx[j] / 3;
+                        double sq = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const double b0 = a.ps * d.B[idxF(d, f, c, t)], b1 = a.ps * d.B[idxF(d, f, c, t + 1)];
+                            sq += b0 * b0 + b1 * b1;
+                        }
+                        q += d.c_area[j] * sq * (1.0 / 3.0);
+                    }
+                    const double rho = rho_s * mu;
+                    const double aux = a.ps * A + 0.25 * q / m;
+                    const double res = fmax(0.0, aux + rho) - rho;
+                    s[V_COMP_AUX2] += aux * aux * m;
+                    s[V_COMP_RES2] += res * res * m;
+                }
+                if (c6) {   // Comp(rho, cong.): :549-559 with :633-636
+                    const double res = a.cong * (rho_s * mu) - a.ps * lc;
+                    s[V_CONG_RES2] += res * res * m;
+                }
+            }
+            if (c2) {       // Dual(alpha): :466-482
+                double x = 0.0;
+                if (t < d.T) x += d.mu[iv] * m;
+                if (t > 0) x -= d.mu[iv - 1] * m;
+                x *= ih;
+                double dsx = 0.0;
+                for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+                    const int f = d.cidx[j] / 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dsx += d.c_gA[j * 3 + c] * d.E[idxF(d, f, c, t)];
+                }
+                x -= dsx;
+                if (t == 0) x -= a.bs * d.mu0[v] / (a.r * d.h);
+                if (t == d.T) x += a.bs * d.mu1[v] / (a.r * d.h);
+                const double aux = (a.r * d.h) * x / m;
+                s[V_DUALAUX2] += aux * aux * m;
+            }
+        }
+    }
+    block_sum<N_VSUMS>(s, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N_VSUMS; ++i) d.partials[(int64_t)i * gridDim.x + blockIdx.x] = s[i];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_kkt_triangle(Dev d, KktArgs a, double *part) {
+    __shared__ double lds[N_FSUMS * 4];
+    const int tile = xcd_tile(blockIdx.x, d.n_ftiles);
+    double s[N_FSUMS];
+#pragma unroll
+    for (int i = 0; i < N_FSUMS; ++i) s[i] = 0.0;
+    const bool c0 = a.mask & 1u, c1 = a.mask & 2u, c3 = a.mask & 8u, c5 = a.mask & 32u;
+    if (tile < d.n_ftiles) {
+        const double sB = a.sz * INV_SQRT3, rho_s = a.ds * a.r;
+        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+            const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
+            if (row >= 3 * d.F || t > d.T) continue;
+            const int f = row / 3, c = row - 3 * f;
+            const double w = d.area_f[f];
+            const int64_t ie = idxF(d, f, c, t);
+            const double B = d.B[ie];
+            if (c0) {
+                double gx = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) gx += d.hat[(f * 3 + k) * 3 + c] * d.phi[idxV(d, d.tri[f * 3 + k], t)];
+                s[F_DX2 - N_VSUMS] += gx * gx * w;
+                s[F_B2 - N_VSUMS] += B * B * w;
+                s[F_RESE2 - N_VSUMS] += (gx - B) * (gx - B) * w;
+            }
+            if (c3 || c5) {
+                const double E = d.E[ie];
+                s[F_E2 - N_VSUMS] += E * E * w;
+                if (c3) {
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (t < d.T) s0 += d.bm[idxM(d, f * 3 + k, 0, c, t)];
+                        if (t > 0) s1 += d.bm[idxM(d, f * 3 + k, 1, c, t - 1)];
+                    }
+                    const double a2 = sB * (s0 + s1);
+                    s[F_AUX2_2 - N_VSUMS] += a2 * a2 * w;
+                    s[F_EAUX2_2 - N_VSUMS] += (E + a2) * (E + a2) * w;
+                }
+                if (c5) {   // Comp(m, rho o B): :528-547 with :624-628
+                    double rn = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int iv = idxV(d, d.tri[f * 3 + k], t);
+                        double r2 = 0.0;
+                        if (t < d.T) r2 += d.mu[iv];
+                        if (t > 0) r2 += d.mu[iv - 1];
+                        rn += 0.5 * rho_s * r2;
+                    }
+                    const double aux = (rn * (1.0 / 3.0)) * (a.ps * B);
+                    const double mm = rho_s * E;
+                    s[F_AUX5_2 - N_VSUMS] += aux * aux * w;
+                    s[F_AUX5M_2 - N_VSUMS] += (aux - mm) * (aux - mm) * w;
+                }
+            }
+            if (c1) {       // z_mid part of Prim(q, z): sz (z_mid - L B)
+                const double sb = sB * B;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (t < d.T) {
+                        const double q = a.sz * (d.zm[idxM(d, f * 3 + k, 0, c, t)] - sb);
+                        s[F_RMID2 - N_VSUMS] += q * q * w;
+                    }
+                    if (t > 0) {
+                        const double q = a.sz * (d.zm[idxM(d, f * 3 + k, 1, c, t - 1)] - sb);
+                        s[F_RMID2 - N_VSUMS] += q * q * w;
+                    }
+                }
+            }
+        }
+    }
+    block_sum<N_FSUMS>(s, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N_FSUMS; ++i) part[(int64_t)i * gridDim.x + blockIdx.x] = s[i];
+    }
+}
+
+// one workgroup per slot: scal[SUMS + first + slot] = sum_blk part[slot][blk]
+__global__ __launch_bounds__(BLOCK) void k_reduce_slots(const double *part, int nblk, double *out) {
+    __shared__ double lds[4];
+    double v[1] = {0.0};
+    for (int g = threadIdx.x; g < nblk; g += BLOCK) v[0] += part[(int64_t)blockIdx.x * nblk + g];
+    block_sum<1>(v, lds);
+    if (threadIdx.x == 0) out[blockIdx.x] = v[0];
+}
+
+int reduce_partials(Ctx *c, const double *part, int n_slots, int nblk, int first) {
+    hipLaunchKernelGGL(k_reduce_slots, dim3(n_slots), dim3(BLOCK), 0, c->stream, part, nblk, c->d.scal + S::SUMS + first);
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
+static int fetch_sums(Ctx *c, int n) {
+    DOTS_HIP(hipMemcpyAsync(c->h_pinned, c->d.scal + S::SUMS, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int kkt_evaluate(Ctx *c, uint32_t mask, double *out) {
+    const Dev &d = c->d;
+    const dots_params &p = c->prm;
+    KktArgs a{mask, p.r, p.scale_z, p.const_d, p.congestion, p.prim_scale, p.dual_scale, p.boundary_scale};
+    const int gv = xcd_grid(d.n_vtiles), gf = xcd_grid(d.n_ftiles);
+    double *part_f = d.partials + (int64_t)N_VSUMS * gv;
+    const bool need_v = mask & (1u | 2u | 4u | 8u | 16u | 64u), need_f = mask & (1u | 2u | 8u | 32u);
+    if (need_v) {
+        hipLaunchKernelGGL(k_kkt_vertex, dim3(gv), dim3(BLOCK), 0, c->stream, d, a);
+        int rc = reduce_partials(c, d.partials, N_VSUMS, gv, 0);
+        if (rc) return rc;
+    }
+    if (need_f) {
+        hipLaunchKernelGGL(k_kkt_triangle, dim3(gf), dim3(BLOCK), 0, c->stream, d, a, part_f);
+        int rc = reduce_partials(c, part_f, N_FSUMS, gf, N_VSUMS);
+        if (rc) return rc;
+    }
+    DOTS_HIP(hipGetLastError());
+    int rc = fetch_sums(c, N_SUMS);
+    if (rc) return rc;
+    const double *s = c->h_pinned;
+    const double T = d.T, T1 = d.T + 1;
+    auto nt = [&](int i) { return s[i] / T; };     // norm_square_time
+    auto nc = [&](int i) { return s[i] / T1; };    // norm_square_center
+    auto ns = [&](int i) { return s[i] / T1; };    // norm_square_space
+    auto nsd = [&](int i) { return s[i] / T; };    // norm_square_space_decouple
+    const double rho2 = (p.dual_scale * p.r) * (p.dual_scale * p.r);
+    const double nan = std::nan("");
+    if (mask & 1u) {
+        const double nsum = std::sqrt(nt(V_DPHI2) + ns(F_DX2)) + std::sqrt(nt(V_A2) + ns(F_B2)) + std::sqrt(nt(V_LAM2));
+        const double res = std::sqrt(nt(V_RESMU2) + ns(F_RESE2));
+        out[0] = res / (c->c_prim_q / p.prim_scale + nsum);
+        out[1] = res / (c->c_prim_q + nsum);
+    }
+    if (mask & 2u) {
+        const double res = std::sqrt(nt(V_RFST2) + nt(V_REND2) + nsd(F_RMID2));
+        out[2] = res / (c->c_prim_z / p.prim_scale + p.norm_d);
+        out[3] = res / (c->c_prim_z + p.norm_d);
+    }
+    if (mask & 4u) {
+        const double res = std::sqrt(nc(V_DUALAUX2));
+        out[4] = res / (c->c_dual_alpha / p.dual_scale + p.norm_boundary);
+        out[5] = res / (c->c_dual_alpha + p.norm_boundary);
+    }
+    if (mask & 8u) {
+        const double nsum = p.r * (std::sqrt(nt(V_MU2) + ns(F_E2)) + std::sqrt(nt(V_AUX1_2) + ns(F_AUX2_2)));
+        const double res = p.r * std::sqrt(nt(V_MUAUX1_2) + ns(F_EAUX2_2));
+        out[6] = res / (c->c_dual_beta / p.dual_scale + nsum);
+        out[7] = res / (c->c_dual_beta + nsum);
+    }
+    if (mask & 16u) {
+        const double nsum = std::sqrt(rho2 * nt(V_MU2)) + std::sqrt(nt(V_COMP_AUX2));
+        out[8] = std::sqrt(nt(V_COMP_RES2)) / (c->c_comp_rho + nsum);
+        out[9] = nan;
+    }
+    if (mask & 32u) {
+        const double nsum = std::sqrt(rho2 * ns(F_E2)) + std::sqrt(ns(F_AUX5_2));
+        out[10] = std::sqrt(ns(F_AUX5M_2)) / (c->c_comp_m + nsum);
+        out[11] = nan;
+    }
+    if (mask & 64u) {
+        const double nsum = std::sqrt(rho2 * nt(V_MU2)) + std::sqrt(p.prim_scale * p.prim_scale * nt(V_LAM2));
+        out[12] = std::sqrt(nt(V_CONG_RES2)) / (c->c_comp_rho + nsum);
+        out[13] = nan;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// objective (solver_socp.py:417-431 as called at :773-775): with phi_s = ps*phi and the boundary
+// term (ds*r)*bnd = ds * (-mu0, +mu1)/h the cost is  ps*ds*( <phi[T],mu1> - <phi[0],mu0> ).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_objective(Dev d) {
+    __shared__ double lds[3 * 4];
+    double s[3] = {0.0, 0.0, 0.0};
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    if (tile < d.n_vtiles) {
+        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+            const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
+            if (v >= d.V || t > d.T) continue;
+            const int iv = idxV(d, v, t);
+            if (t == 0) s[0] += d.phi[iv] * d.mu0[v];
+            if (t == d.T) s[1] += d.phi[iv] * d.mu1[v];
+            if (t < d.T) s[2] += d.lam[iv] * d.lam[iv] * d.mass_v[v];
+        }
+    }
+    block_sum<3>(s, lds);
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 3; ++i) d.partials[(int64_t)i * gridDim.x + blockIdx.x] = s[i];
+}
+
+int objective_evaluate(Ctx *c, double *out) {
+    const Dev &d = c->d;
+    const dots_params &p = c->prm;
+    const int gv = xcd_grid(d.n_vtiles);
+    hipLaunchKernelGGL(k_objective, dim3(gv), dim3(BLOCK), 0, c->stream, d);
+    int rc = reduce_partials(c, d.partials, 3, gv, 0);
+    if (rc) return rc;
+    rc = fetch_sums(c, 3);
+    if (rc) return rc;
+    const double *s = c->h_pinned;
+    const double cost = p.prim_scale * p.dual_scale * p.boundary_scale * (s[1] - s[0]);
+    const double cong = p.congestion * p.prim_scale / p.dual_scale;
+    out[0] = cost;
+    out[1] = (cong > 1e-10) ? cost - (p.prim_scale * p.prim_scale * s[2] / d.T) / (2.0 * cong) : cost;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// norm_square_weight of one array (solver_socp.py:875-878 with the partials of :215-218)
+//   kind 0 node (mass, /(T+1))  1 interval (mass, /T)  2 triangle (area, /(T+1))  3 corner (area, /T)
+//   part 1 / 2 with DOTS_PHI: grad_time(phi) / grad_space(phi)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_norm(Dev d, const double *x, int kind, int part) {
+    __shared__ double lds[4];
+    double s[1] = {0.0};
+    const bool vert = (kind <= 1 && part != 2);
+    const int ntiles = vert ? d.n_vtiles : (kind == 3 ? 6 * d.n_ftiles : d.n_ftiles);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+            const int64_t row = (int64_t)tile * d.VT + (e >> d.tp_shift);
+            const int t = e & (d.TP - 1);
+            if (vert) {
+                if (row >= d.V) continue;
+                const int iv = idxV(d, (int)row, t);
+                double val = 0.0;
+                if (part == 1) {
+                    if (t >= d.T) continue;
+                    val = (x[iv + 1] - x[iv]) / d.h;
+                } else {
+                    if (t >= (kind == 0 ? d.T + 1 : d.T)) continue;
+                    val = x[iv];
+                }
+                s[0] += val * val * d.mass_v[row];
+            } else if (kind == 3) {
+                if (row >= (int64_t)18 * d.F || t >= d.T) continue;
+                const double val = x[(row << d.tp_shift) + t];
+                s[0] += val * val * d.area_f[row / 18];
+            } else {
+                if (row >= (int64_t)3 * d.F || t > d.T) continue;
+                const int f = (int)(row / 3), c = (int)(row - 3 * (row / 3));
+                double val;
+                if (part == 2) {
+                    val = 0.0;
+                    for (int k = 0; k < 3; ++k) val += d.hat[(f * 3 + k) * 3 + c] * x[idxV(d, d.tri[f * 3 + k], t)];
+                } else {
+                    val = x[(row << d.tp_shift) + t];
+                }
+                s[0] += val * val * d.area_f[f];
+            }
+        }
+    }
+    block_sum<1>(s, lds);
+    if (threadIdx.x == 0) d.partials[blockIdx.x] = s[0];
+}
+
+int norm_square(Ctx *c, int id, int part, double *out) {
+    const Dev &d = c->d;
+    const int kind = array_kind(id);
+    if (part != 0 && id != DOTS_PHI) {
+        set_error("part != 0 is only defined for DOTS_PHI");
+        return DOTS_ERR_ARGUMENT;
+    }
+    const int g = 512;
+    hipLaunchKernelGGL(k_norm, dim3(g), dim3(BLOCK), 0, c->stream, d, c->arr(id), kind, part);
+    int rc = reduce_partials(c, d.partials, 1, g, 0);
+    if (rc) return rc;
+    rc = fetch_sums(c, 1);
+    if (rc) return rc;
+    double avg = (kind == 0 || kind == 2) ? d.T + 1 : d.T;
+    if (part == 1) avg = d.T;
+    if (part == 2) avg = d.T + 1;
+    *out = c->h_pinned[0] / avg;
+    return 0;
+}
+
+}  // namespace dots

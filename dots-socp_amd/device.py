@@ -1,0 +1,184 @@
+"""DeviceProblem: one device-resident DOTs-SOCP problem behind the C ABI.
+
+Thin object wrapper over ``libdotsocp_hip.so``: builds the problem description from the host-side
+plan (``geometry.build_plan``), owns the context handle, and exposes the calls of
+``include/dots_socp_hip.h`` with numpy arrays in the reference's layouts.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .geometry import DevicePlan, build_plan
+
+STATE_NAMES = tuple(_lib.ARRAY_IDS)
+
+
+def _ptr(a, ctype):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+class DeviceProblem:
+    def __init__(self, n_time, geometry, lap_solver="spacetime_pcg", device=0, reorder=True, plan: DevicePlan | None = None):
+        self.lib = _lib.load()
+        self.plan = plan if plan is not None else build_plan(n_time, geometry, reorder=reorder)
+        p = self.plan
+        self.T, self.V, self.F = p.n_time, p.n_vertices, p.n_triangles
+        if lap_solver not in _lib.LAP_SOLVERS:
+            raise ValueError(f"lap_solver must be one of {list(_lib.LAP_SOLVERS)}")
+        self.lap_solver = lap_solver
+        d = _lib.ProblemDesc()
+        d.abi_version = _lib.ABI_VERSION
+        d.device = int(device)
+        d.n_time, d.n_vertices, d.n_triangles = p.n_time, p.n_vertices, p.n_triangles
+        d.n_corners = int(p.corner_idx.size)
+        d.lap_nnz = int(p.lap_val.size)
+        d.lap_solver = _lib.LAP_SOLVERS[lap_solver]
+        d.triangles = _ptr(p.triangles, C.c_int32)
+        d.hat_grad = _ptr(p.hat_grad, C.c_double)
+        d.area_tri = _ptr(p.area_tri, C.c_double)
+        d.mass_vert = _ptr(p.mass_vert, C.c_double)
+        d.corner_ptr = _ptr(p.corner_ptr, C.c_int32)
+        d.corner_idx = _ptr(p.corner_idx, C.c_int32)
+        d.lap_rowptr = _ptr(p.lap_rowptr, C.c_int32)
+        d.lap_col = _ptr(p.lap_col, C.c_int32)
+        d.lap_val = _ptr(p.lap_val, C.c_double)
+        d.mu0 = _ptr(p.mu0, C.c_double)
+        d.mu1 = _ptr(p.mu1, C.c_double)
+        d.perm_vert = _ptr(p.perm_vert, C.c_int32)
+        d.perm_tri = _ptr(p.perm_tri, C.c_int32)
+        d.time_modes = _ptr(p.time_modes, C.c_double)
+        d.time_eigs = _ptr(p.time_eigs, C.c_double)
+        self._h = C.c_void_p()
+        _lib.check(self.lib.dots_create(C.byref(d), C.byref(self._h)), "dots_create")
+        self.params = _lib.Params()
+        _lib.check(self.lib.dots_get_params(self._h, C.byref(self.params)), "dots_get_params")
+
+    # ---- lifecycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.dots_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- shapes of the reference layouts
+    def shape(self, name):
+        T, V, F = self.T, self.V, self.F
+        if name == "phi":
+            return (T + 1, V)
+        if name in ("B", "E"):
+            return (T + 1, F, 3)
+        if name in ("z_mid", "beta_mid"):
+            return (T, 2, 3, F, 3)
+        return (T, V)
+
+    # ---- parameters
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.params, k):
+                raise AttributeError(k)
+            setattr(self.params, k, v)
+        _lib.check(self.lib.dots_set_params(self._h, C.byref(self.params)), "dots_set_params")
+
+    # ---- state transfer
+    def upload(self, name, array):
+        a = np.ascontiguousarray(array, dtype=np.float64)
+        if a.shape != self.shape(name):
+            raise ValueError(f"{name}: expected shape {self.shape(name)}, got {a.shape}")
+        _lib.check(self.lib.dots_upload(self._h, _lib.ARRAY_IDS[name], _ptr(a, C.c_double), a.size), f"upload {name}")
+
+    def download(self, name):
+        out = np.empty(self.shape(name), dtype=np.float64)
+        _lib.check(self.lib.dots_download(self._h, _lib.ARRAY_IDS[name], _ptr(out, C.c_double), out.size), f"download {name}")
+        return out
+
+    def download_all(self):
+        return {n: self.download(n) for n in STATE_NAMES}
+
+    # ---- the hot loop
+    def step(self, n_iters=1):
+        st = _lib.StepStats()
+        _lib.check(self.lib.dots_step(self._h, int(n_iters), C.byref(st)), "dots_step")
+        return st
+
+    def run_phase(self, phase):
+        st = _lib.StepStats()
+        _lib.check(self.lib.dots_run_phase(self._h, _lib.PHASES[phase], C.byref(st)), f"phase {phase}")
+        return st
+
+    def kkt(self, conditions):
+        """Evaluate the listed KKT conditions; returns {i: [value, value_at_unit_scale or None]}."""
+        mask = 0
+        for i in conditions:
+            mask |= 1 << int(i)
+        out = np.full(14, np.nan)
+        _lib.check(self.lib.dots_kkt(self._h, mask, _ptr(out, C.c_double)), "dots_kkt")
+        res = {}
+        for i in conditions:
+            second = float(out[2 * i + 1])
+            res[int(i)] = [float(out[2 * i]), None if i >= 4 else second]
+        return res
+
+    def objective(self):
+        out = np.zeros(2)
+        _lib.check(self.lib.dots_objective(self._h, _ptr(out, C.c_double)), "dots_objective")
+        return float(out[0]), float(out[1])
+
+    def adjust_penalty(self, factor):
+        _lib.check(self.lib.dots_adjust_penalty(self._h, float(factor)), "dots_adjust_penalty")
+
+    def scale_z(self, z_mul, beta_mul, scale_z_new):
+        _lib.check(self.lib.dots_scale_z(self._h, float(z_mul), float(beta_mul), float(scale_z_new)), "dots_scale_z")
+
+    def scale_arrays(self, names, factor):
+        mask = 0
+        for n in names:
+            mask |= 1 << _lib.ARRAY_IDS[n]
+        _lib.check(self.lib.dots_scale_arrays(self._h, mask, float(factor)), "dots_scale_arrays")
+
+    def norm_square(self, name, part=0):
+        out = C.c_double()
+        _lib.check(self.lib.dots_norm_square(self._h, _lib.ARRAY_IDS[name], int(part), C.byref(out)), "dots_norm_square")
+        return out.value
+
+    def apply_operator(self, op, x, scale=1.0):
+        shapes = {
+            "grad_time": ("phi", "A"), "div_time": ("A", "phi"), "time_avg_adjoint": ("A", "phi"),
+            "grad_space": ("phi", "B"), "div_space": ("B", "phi"), "decouple": ("B", "z_mid"),
+            "decouple_adjoint": ("z_mid", "B"), "laplacian_apply": ("phi", "phi"),
+        }
+        sin, sout = shapes[op]
+        a = np.ascontiguousarray(x, dtype=np.float64)
+        if a.shape != self.shape(sin):
+            raise ValueError(f"{op}: expected input shape {self.shape(sin)}, got {a.shape}")
+        out = np.empty(self.shape(sout), dtype=np.float64)
+        _lib.check(
+            self.lib.dots_apply_operator(self._h, _lib.OPERATORS[op], float(scale), _ptr(a, C.c_double), a.size,
+                                         _ptr(out, C.c_double), out.size),
+            f"operator {op}",
+        )
+        return out
+
+    def bench_kernel(self, which=0, reps=50):
+        ms, nbytes = C.c_double(), C.c_double()
+        _lib.check(self.lib.dots_bench_kernel(self._h, int(which), int(reps), C.byref(ms), C.byref(nbytes)), "dots_bench_kernel")
+        return ms.value, nbytes.value
+
+    def sync(self):
+        _lib.check(self.lib.dots_sync(self._h), "dots_sync")
+
+    def device_bytes(self):
+        return int(self.lib.dots_device_bytes(self._h))

@@ -1,0 +1,156 @@
+"""Host-side operator assembly for the HIP path (vectorised numpy, runs once per solve).
+
+Produces the flat arrays of ``dots_problem_desc`` (include/dots_socp_hip.h).  It covers what the
+reference computes in ``utils/surface_pre_computations_socp.py:11-132`` and
+``socp/solver_socp.py:102-113,161-192`` -- triangle areas, hat-function gradients, vertex masses,
+the surface stiffness matrix, the vertex<->corner incidence -- but keeps every constant at its
+natural size (per triangle / per vertex / per corner) instead of broadcasting it to the size of
+the state, and never builds the Kronecker incidence matrices: the kernels index the corner lists.
+
+Also computes an optional locality-preserving renumbering (reverse Cuthill-McKee on the mesh
+graph) so that neighbouring rows sit in neighbouring tiles / the same XCD's L2.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+
+@dataclass
+class DevicePlan:
+    n_time: int
+    n_vertices: int
+    n_triangles: int
+    triangles: np.ndarray     # (F,3) int32, device numbering
+    hat_grad: np.ndarray      # (F,3,3) float64   [f, corner, xyz]
+    area_tri: np.ndarray      # (F,)
+    mass_vert: np.ndarray     # (V,)  = incident area / 3
+    corner_ptr: np.ndarray    # (V+1,) int32
+    corner_idx: np.ndarray    # (3F,)  int32, f*3+k
+    lap_rowptr: np.ndarray    # (V+1,) int32
+    lap_col: np.ndarray       # (nnz,) int32
+    lap_val: np.ndarray       # (nnz,) float64,  K = G^T diag(area) G = - cotangent Laplacian
+    mu0: np.ndarray           # (V,) device numbering
+    mu1: np.ndarray
+    perm_vert: np.ndarray | None   # device vertex i = caller vertex perm_vert[i]
+    perm_tri: np.ndarray | None
+    time_modes: np.ndarray    # (T+1, T+1) Q[t, a]
+    time_eigs: np.ndarray     # (T+1,) sigma_a >= 0
+    area_mesh: float
+
+
+def hat_gradients(vertices, triangles):
+    """Triangle areas and the gradients of the three hat functions of every triangle.
+
+    The gradient of the hat function of corner k is the altitude vector from the opposite edge to
+    that corner divided by its squared length (same quantity as the reference's ``base_function``,
+    surface_pre_computations_socp.py:31-37)."""
+    v = np.asarray(vertices, dtype=np.float64)
+    t = np.asarray(triangles)
+    p = v[t]                                             # (F, 3, 3)
+    area = 0.5 * np.linalg.norm(np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 1]), axis=1)
+    g = np.empty_like(p)
+    for k in range(3):
+        a, b = p[:, (k + 1) % 3], p[:, (k + 2) % 3]
+        e = b - a
+        w = p[:, k] - a
+        alt = w - e * (np.einsum("ij,ij->i", w, e) / np.einsum("ij,ij->i", e, e))[:, None]
+        g[:, k] = alt / np.einsum("ij,ij->i", alt, alt)[:, None]
+    return area, g
+
+
+def stiffness_matrix(n_vertices, triangles, area, hat):
+    """K = G^T diag(area) G  (V x V, CSR, sorted, duplicates summed): minus the cotangent Laplacian."""
+    t = np.asarray(triangles)
+    loc = area[:, None, None] * np.einsum("fic,fjc->fij", hat, hat)     # (F,3,3)
+    rows = np.broadcast_to(t[:, :, None], loc.shape).reshape(-1)
+    cols = np.broadcast_to(t[:, None, :], loc.shape).reshape(-1)
+    K = sp.coo_matrix((loc.reshape(-1), (rows, cols)), shape=(n_vertices, n_vertices)).tocsr()
+    K.sum_duplicates()
+    K.sort_indices()
+    return K
+
+
+def corner_lists(n_vertices, triangles):
+    """vertex -> corners CSR.  Corners of a vertex are ordered by (k, f), i.e. by the reference's
+    corner index i = k*F + f (surface_pre_computations_socp.py:114-118)."""
+    t = np.asarray(triangles)
+    F = t.shape[0]
+    vert_of_corner = t.T.reshape(-1)                                    # i = k*F + f
+    order = np.argsort(vert_of_corner, kind="stable")
+    k, f = np.divmod(order, F)
+    ptr = np.zeros(n_vertices + 1, dtype=np.int64)
+    np.add.at(ptr, vert_of_corner + 1, 1)
+    return np.cumsum(ptr).astype(np.int32), (f * 3 + k).astype(np.int32)
+
+
+def time_modes(n_time):
+    """Orthonormal eigenvectors Q[t, a] and eigenvalues sigma_a >= 0 of minus the Neumann second
+    difference on n_time+1 nodes with step h = 1/n_time (the matrix of
+    laplacian_inverse_socp.py:15-26): the DCT-II basis."""
+    n = n_time + 1
+    h = 1.0 / n_time
+    a = np.arange(n)
+    j = np.arange(n)
+    Q = np.cos(np.pi * np.outer(j + 0.5, a) / n) * np.sqrt(np.where(a == 0, 1.0, 2.0) / n)[None, :]
+    sigma = (2.0 - 2.0 * np.cos(np.pi * a / n)) / (h * h)
+    return Q, sigma
+
+
+def locality_order(K, triangles):
+    """Reverse Cuthill-McKee numbering of the vertices; triangles sorted by their smallest new vertex."""
+    perm_v = np.asarray(reverse_cuthill_mckee(K, symmetric_mode=True), dtype=np.int64)
+    inv = np.empty_like(perm_v)
+    inv[perm_v] = np.arange(perm_v.size)
+    t_new = inv[np.asarray(triangles)]
+    perm_f = np.argsort(t_new.min(axis=1), kind="stable")
+    return perm_v, perm_f
+
+
+def build_plan(n_time, geometry, reorder=True) -> DevicePlan:
+    vertices = np.asarray(geometry["vertices"], dtype=np.float64)
+    triangles = np.asarray(geometry["triangles"]).astype(np.int64)
+    mu0 = np.asarray(geometry["mu0"], dtype=np.float64)
+    mu1 = np.asarray(geometry["mu1"], dtype=np.float64)
+    V, F = vertices.shape[0], triangles.shape[0]
+    if triangles.min() < 0 or triangles.max() >= V:
+        raise ValueError("triangle index out of range")
+    if mu0.shape != (V,) or mu1.shape != (V,):
+        raise ValueError("mu0/mu1 must have one entry per vertex")
+
+    perm_v = perm_f = None
+    if reorder:
+        area0, hat0 = hat_gradients(vertices, triangles)
+        perm_v, perm_f = locality_order(stiffness_matrix(V, triangles, area0, hat0), triangles)
+        inv = np.empty_like(perm_v)
+        inv[perm_v] = np.arange(V)
+        vertices = vertices[perm_v]
+        triangles = inv[triangles[perm_f]]
+        mu0, mu1 = mu0[perm_v], mu1[perm_v]
+
+    area, hat = hat_gradients(vertices, triangles)
+    if not np.all(area > 0):
+        raise ValueError("degenerate triangle (zero area)")
+    mass = np.zeros(V)
+    for k in range(3):
+        np.add.at(mass, triangles[:, k], area)
+    mass /= 3.0
+    if not np.all(mass > 0):
+        raise ValueError("isolated vertex (no incident triangle)")
+    K = stiffness_matrix(V, triangles, area, hat)
+    cptr, cidx = corner_lists(V, triangles)
+    Q, sigma = time_modes(n_time)
+    c = np.ascontiguousarray
+    return DevicePlan(
+        n_time=int(n_time), n_vertices=V, n_triangles=F,
+        triangles=c(triangles.astype(np.int32)), hat_grad=c(hat), area_tri=c(area), mass_vert=c(mass),
+        corner_ptr=c(cptr), corner_idx=c(cidx),
+        lap_rowptr=c(K.indptr.astype(np.int32)), lap_col=c(K.indices.astype(np.int32)), lap_val=c(K.data.astype(np.float64)),
+        mu0=c(mu0), mu1=c(mu1),
+        perm_vert=None if perm_v is None else c(perm_v.astype(np.int32)),
+        perm_tri=None if perm_f is None else c(perm_f.astype(np.int32)),
+        time_modes=c(Q), time_eigs=c(sigma), area_mesh=float(area.sum()),
+    )

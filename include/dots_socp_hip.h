@@ -1,0 +1,204 @@
+/*
+ * dots_socp_hip.h -- C ABI of libdotsocp_hip.so, the MI355X (gfx950) implementation of the
+ * DOTs-SOCP ALM hot path.
+ *
+ * The reference is pure Python (no FFI exists in it); these entry points are what a ctypes
+ * binding placed at the reference's solver plug-in boundary would bind.  Each function names the
+ * reference code it replaces (paths relative to the reference root, file:line).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative dots_status otherwise; the message of the
+ *     last failure is available from dots_last_error() (per thread).
+ *   - host pointers are borrowed for the duration of the call only; device memory belongs to the
+ *     context.  One host thread per context.
+ *   - host-side state arrays use the REFERENCE layouts and fp64:
+ *       phi                          (T+1, V)
+ *       A, lambda_c, mu, z_fst, z_end, beta_fst, beta_end   (T, V)
+ *       B, E                         (T+1, F, 3)
+ *       z_mid, beta_mid              (T, 2, 3, F, 3)
+ *     the device layout (vertex/triangle-major, time fastest) is internal.
+ *   - no C++ exceptions, torch types or Python objects cross this boundary.
+ */
+#ifndef DOTS_SOCP_HIP_H
+#define DOTS_SOCP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DOTS_ABI_VERSION 1
+
+typedef struct dots_ctx dots_ctx;
+
+enum dots_status {
+    DOTS_OK = 0,
+    DOTS_ERR_ARGUMENT = -1,
+    DOTS_ERR_HIP = -2,
+    DOTS_ERR_NO_DEVICE = -3,
+    DOTS_ERR_NOT_CONVERGED = -4,
+    DOTS_ERR_STATE = -5
+};
+
+/* state arrays, same names as SolutionSocpData (dot_surface_socp/utils/type.py:22-38) */
+enum dots_array {
+    DOTS_PHI = 0, DOTS_A, DOTS_B, DOTS_LAMBDA_C, DOTS_Z_FST, DOTS_Z_MID, DOTS_Z_END,
+    DOTS_MU, DOTS_E, DOTS_BETA_FST, DOTS_BETA_MID, DOTS_BETA_END,
+    DOTS_N_ARRAYS
+};
+
+/* the seven KKT residuals in the order of solver_socp.py:590-640 */
+enum dots_kkt_id {
+    DOTS_KKT_PRIM_Q = 0, DOTS_KKT_PRIM_Z, DOTS_KKT_DUAL_ALPHA, DOTS_KKT_DUAL_BETA,
+    DOTS_KKT_COMP_RHO_FQ, DOTS_KKT_COMP_M_RHO_B, DOTS_KKT_COMP_CONGESTION,
+    DOTS_N_KKT
+};
+
+/* which Laplacian solver runs in step 1 (replaces laplacian_inverse_socp.py:11-61) */
+enum dots_lap_solver {
+    DOTS_LAP_SPACETIME_PCG = 0, /* Jacobi-PCG on the assembled space-time operator            */
+    DOTS_LAP_MODAL_PCG = 1      /* time eigen-modes decoupled (DCT), batched shifted-surface PCG */
+};
+
+/*
+ * Problem description: the outputs of the reference's operator assembly
+ * (utils/surface_pre_computations_socp.py:11-132, solver_socp.py:102-113,161-192) as flat arrays.
+ * The host side (dots-socp_amd/geometry.py) builds them; all index arrays are 0-based int32.
+ */
+typedef struct dots_problem_desc {
+    int32_t abi_version;     /* DOTS_ABI_VERSION */
+    int32_t device;          /* HIP device ordinal */
+    int32_t n_time;          /* T: number of time intervals (T+1 nodes) */
+    int32_t n_vertices;      /* V */
+    int32_t n_triangles;     /* F */
+    int32_t n_corners;       /* = 3 F, length of the vertex->corner lists */
+    int32_t lap_nnz;         /* non-zeros of the surface stiffness matrix */
+    int32_t lap_solver;      /* enum dots_lap_solver */
+
+    const int32_t *triangles;    /* [F][3]                                                     */
+    const double *hat_grad;      /* [F][3 corners][3 xyz] hat-function gradients (:31-37)       */
+    const double *area_tri;      /* [F]                                                        */
+    const double *mass_vert;     /* [V]  = (sum of incident triangle areas) / 3  (solver_socp.py:112) */
+    const int32_t *corner_ptr;   /* [V+1] vertex -> corner list (CSR)                           */
+    const int32_t *corner_idx;   /* [3F]  entries f*3+k, the corners (f,k) with triangles[f][k]==v */
+    const int32_t *lap_rowptr;   /* [V+1]  K = -cotangent Laplacian (= G^T diag(area) G), CSR, SPD-semidefinite */
+    const int32_t *lap_col;      /* [nnz]                                                       */
+    const double *lap_val;       /* [nnz]                                                       */
+    const double *mu0;           /* [V] boundary masses (geometry["mu0"], solver_socp.py:267-270) */
+    const double *mu1;           /* [V]                                                         */
+    const int32_t *perm_vert;    /* [V] device vertex i is caller vertex perm_vert[i]; NULL = identity */
+    const int32_t *perm_tri;     /* [F] device triangle i is caller triangle perm_tri[i]; NULL = identity */
+    const double *time_modes;    /* [(T+1)*(T+1)] row-major Q[t][a]: orthonormal eigenvectors of the Neumann
+                                    time Laplacian (laplacian_inverse_socp.py:15-31); NULL unless MODAL */
+    const double *time_eigs;     /* [T+1] eigenvalues sigma_a >= 0 of -L_time;  NULL unless MODAL */
+} dots_problem_desc;
+
+/* Scalars the host control logic owns (solver_socp.py:97,318-321 and the kwargs of :25-41). */
+typedef struct dots_params {
+    double r;              /* penalty                                   */
+    double scale_z;        /* scale_factor_z                            */
+    double const_d;        /* constant_d                                */
+    double norm_d;         /* norm_constant_d (:297,380)                */
+    double norm_boundary;  /* norm_boundary (:296)                      */
+    double congestion;
+    double tau;
+    double eps;
+    double prim_scale;
+    double dual_scale;
+    double boundary_scale; /* multiplies the boundary term (-mu0, +mu1)/(r h); 1 unless constant scaling (:357-358) */
+    double cg_tol;         /* PCG stops when r^T M^-1 r <= cg_tol^2 * b^T M^-1 b */
+    int32_t cg_max_iter;
+    int32_t reserved;
+} dots_params;
+
+typedef struct dots_step_stats {
+    int32_t alm_iterations;     /* iterations performed by this call                     */
+    int32_t cg_iterations;      /* PCG iterations summed over them                        */
+    int32_t cg_last_iterations; /* PCG iterations of the last one                         */
+    int32_t cg_not_converged;   /* number of solves that hit cg_max_iter                  */
+    double cg_last_rel_residual;
+    double ms_rhs;              /* hipEvent times summed over the call, milliseconds      */
+    double ms_laplacian;
+    double ms_soc;
+    double ms_q_lambda_multiplier;
+    double ms_total;
+} dots_step_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int dots_abi_version(void);
+const char *dots_last_error(void);
+
+/* Build the device-resident problem: replaces the setup of solver_socp.py:96-313 (constants,
+ * Laplacian operator, zero-initialised state as :239-250 with an empty init_solution). */
+int dots_create(const dots_problem_desc *desc, dots_ctx **out);
+int dots_destroy(dots_ctx *ctx);
+int dots_set_params(dots_ctx *ctx, const dots_params *p);
+int dots_get_params(dots_ctx *ctx, dots_params *p);
+int dots_sync(dots_ctx *ctx);
+
+/* ---- state transfer (init_solution in, SolutionSocpData out; solver_socp.py:239-250,855-869) */
+int dots_upload(dots_ctx *ctx, int array_id, const double *host, int64_t count);
+int dots_download(dots_ctx *ctx, int array_id, double *host, int64_t count);
+int64_t dots_array_count(dots_ctx *ctx, int array_id);
+
+/* ---- the hot loop ------------------------------------------------------------------------ */
+/* n ALM iterations, steps 1-3 of solver_socp.py:674-722 (is_palm = False), device resident. */
+int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
+
+/* single phases of one iteration, for per-function parity tests */
+enum dots_phase {
+    DOTS_PHASE_LAPLACIAN = 0,        /* vanilla_solve_laplacian  solver_socp.py:976-986 + laplacian_inverse_socp.py:52-61 */
+    DOTS_PHASE_SOC_PROJECTION = 1,   /* vanilla_solve_proj_soc   solver_socp.py:988-1042 */
+    DOTS_PHASE_Q_LAMBDA_MULT = 2     /* grad_time/grad_space + vanilla_solve_q_lambda :709-714,1044-1065 and the multiplier update :716-722 */
+};
+int dots_run_phase(dots_ctx *ctx, int phase, dots_step_stats *stats);
+
+/* KKT residuals (closures of solver_socp.py:433-559 as wired at :589-643).  mask: bit i set =
+ * evaluate condition i.  out[2*i], out[2*i+1] = the two values the reference's wrapper returns
+ * (with prim/dual scale, with scale 1); entries of conditions not in mask are left untouched.
+ * For conditions 4..6 the second value does not exist in the reference and is set to NaN. */
+int dots_kkt(dots_ctx *ctx, uint32_t mask, double *out /* [2*DOTS_N_KKT] */);
+
+/* objective_functional (solver_socp.py:417-431) as called at :773-775/:829-831:
+ * out[0] = transportation cost, out[1] = Lagrangian / objective value. */
+int dots_objective(dots_ctx *ctx, double *out /* [2] */);
+
+/* scaling tools (solver_socp.py:367-395).  These update the arrays only; the caller keeps
+ * r / scale_z / const_d in dots_params consistent (dots_set_params). */
+int dots_adjust_penalty(dots_ctx *ctx, double factor);             /* adjust_penalty :367-371: 5 dual arrays /= factor */
+int dots_scale_z(dots_ctx *ctx, double z_mul, double beta_mul, double scale_z_new);
+        /* scale_variable_z :373-395: z *= z_mul, beta *= beta_mul, mu = scale_z_new*(beta_fst-beta_end),
+           E = -L^T(beta_mid; scale_z_new) */
+int dots_scale_arrays(dots_ctx *ctx, uint32_t array_mask, double factor); /* x *= factor for every array in mask (scale_prim_dual :352-358) */
+
+/* weighted squared norms norm_square_* (solver_socp.py:875-878, :215-218) of one state array,
+ * and of dt_phi / dx_phi when array_id is DOTS_PHI with part = 1 / 2. */
+int dots_norm_square(dots_ctx *ctx, int array_id, int part, double *out);
+
+/* ---- standalone operators (rows a4-a6 of SURVEY.md section 8a), host in / host out, for tests */
+enum dots_operator {
+    DOTS_OP_GRAD_TIME = 0,       /* (T+1,V)      -> (T,V)        solver_socp.py:881-884 */
+    DOTS_OP_DIV_TIME,            /* (T,V)        -> (T+1,V)      :886-896 */
+    DOTS_OP_GRAD_SPACE,          /* (T+1,V)      -> (T+1,F,3)    :898-907 */
+    DOTS_OP_DIV_SPACE,           /* (T+1,F,3)    -> (T+1,V)      :909-921 */
+    DOTS_OP_DECOUPLE,            /* (T+1,F,3)    -> (T,2,3,F,3)  :923-942 (scale) */
+    DOTS_OP_DECOUPLE_ADJOINT,    /* (T,2,3,F,3)  -> (T+1,F,3)    :944-959 (scale) */
+    DOTS_OP_TIME_AVG_ADJOINT,    /* (T,V)        -> (T+1,V)      :961-974 */
+    DOTS_OP_LAPLACIAN_APPLY      /* (T+1,V)      -> (T+1,V)   x -> K x, the operator step 1 inverts (sign: K = -Laplacian + eps M) */
+};
+int dots_apply_operator(dots_ctx *ctx, int op, double scale, const double *in, int64_t n_in, double *out, int64_t n_out);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* Launch the dominant kernel (the PCG operator application) `reps` times on the context's stream
+ * between two hipEvents and return the average milliseconds per launch and the algorithmic bytes
+ * one launch moves (DESIGN.md section "roofline"). */
+int dots_bench_kernel(dots_ctx *ctx, int which, int reps, double *ms_per_launch, double *bytes_per_launch);
+
+/* device memory in use by the context, bytes */
+int64_t dots_device_bytes(dots_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOTS_SOCP_HIP_H */

@@ -169,7 +169,7 @@ def run_reference(ref, geometry, n_time, **kw):
     return sol, hist
 
 
-def save_run(name, geometry, n_time, kw, sol, hist, keep):
+def save_run(name, geometry, n_time, kw, sol, hist, keep, scale_factor=None):
     out = dict(vertices=geometry["vertices"], triangles=geometry["triangles"], mu0=geometry["mu0"], mu1=geometry["mu1"],
                n_time=np.array(n_time))
     for k, val in kw.items():
@@ -186,6 +186,8 @@ def save_run(name, geometry, n_time, kw, sol, hist, keep):
     for k, val in hist.history.items():
         out["hist_" + k.replace(" ", "_")] = np.asarray(val, dtype=np.float64)
     out["last_iteration"] = np.array(int(hist.kkt_iteration[-1]))
+    if scale_factor is not None:  # interface.py:303-308 reports cost / scale_factor**2
+        out["scale_factor"] = np.array(scale_factor)
     if sol.get("checkpoints"):
         out["ckpt_iteration"] = np.array([c["iteration"] for c in sol["checkpoints"]])
         out["ckpt_mu"] = np.stack([c["mu"] for c in sol["checkpoints"]])
@@ -198,7 +200,7 @@ ALL_STATE = ("phi", "A", "B", "lambda_c", "z_fst", "z_mid", "z_end", "mu", "E", 
 SMALL_STATE = ("phi", "A", "lambda_c", "mu")
 
 
-def make_runs(ref, full):
+def make_runs(ref, full, small=True):
     tm = tiny_meshes(ref)
     cases = []
     g_ico1, _ = geometry_for(ref, *tm["ico1"])
@@ -219,21 +221,23 @@ def make_runs(ref, full):
     cases.append(("ico2_T15_cong_tol1e-3", g_ico2, 15, dict(nit=3000, tol=1e-3, congestion=0.1), SMALL_STATE))
     cases.append(("ico2_T15_ckpt_tol1e-3", g_ico2, 15, dict(nit=3000, tol=1e-3, tol_checkpoints=[1e-1, 1e-2]), SMALL_STATE))
     cases.append(("torus_T7_tol1e-4", g_tor, 7, dict(nit=5000, tol=1e-4), SMALL_STATE))
+    if not small:
+        cases = []
     if full:
         # the survey's headline cases: reference plane n=20, T=31, tol=1e-3
         v, t, _ = ref.plane_mesh.generate_mesh(20)
         t = np.asarray(t)
-        g20, _ = meshes.make_geometry(v, t, normalize=True)
+        g20, scale20 = meshes.make_geometry(v, t, normalize=True)
         mu0, mu1 = ref.plane_setting.get_mu(meshes.vertex_areas(v.shape[0], t, meshes.triangle_areas(v, t)), v)
         g20["mu0"], g20["mu1"] = mu0 / mu0.sum(), mu1 / mu1.sum()
-        cases.append(("refplane20_T31_tol1e-3", g20, 31, dict(nit=1000, tol=1e-3), SMALL_STATE))
-        cases.append(("refplane20_T31_cong_tol1e-3", g20, 31, dict(nit=1000, tol=1e-3, congestion=0.1), SMALL_STATE))
-    for name, g, T, kw, keep in cases:
+        cases.append(("refplane20_T31_tol1e-3", g20, 31, dict(nit=1000, tol=1e-3), SMALL_STATE, scale20))
+        cases.append(("refplane20_T31_cong_tol1e-3", g20, 31, dict(nit=1000, tol=1e-3, congestion=0.1), SMALL_STATE, scale20))
+    for name, g, T, kw, keep, *rest in cases:
         kw_run = dict(kw)
         if "tol_checkpoints" in kw_run:
             kw_run["tol_checkpoints"] = list(kw_run["tol_checkpoints"])
         sol, hist = run_reference(ref, g, T, **kw_run)
-        save_run(name, g, T, kw, sol, hist, keep)
+        save_run(name, g, T, kw, sol, hist, keep, *rest)
 
 
 def main(argv):
@@ -243,7 +247,7 @@ def main(argv):
         for i, (name, (v, t)) in enumerate(tiny_meshes(ref).items()):
             make_ops(ref, name, v, t, n_time=(4, 6, 5)[i], seed=100 + i)
     if "runs" in what or "full" in what:
-        make_runs(ref, full="full" in what)
+        make_runs(ref, full="full" in what, small="runs" in what)
 
 
 if __name__ == "__main__":

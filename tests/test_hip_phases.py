@@ -1,0 +1,223 @@
+"""GPU parity, function by function: HIP path (through the C ABI) vs the CPU oracle and the
+reference's own golden vectors, on the small golden meshes."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, load_oracle
+
+pytestmark = pytest.mark.gpu
+
+O = load_oracle()
+OPS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN_DIR, "ops_*.npz")))
+STATE = ("phi", "A", "B", "lambda_c", "z_fst", "z_mid", "z_end", "mu", "E", "beta_fst", "beta_mid", "beta_end")
+FP_TOL = 1e-12   # fp64 element-wise kernels vs numpy: summation order only
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def remove_gauge(phi, mass_v):
+    w = np.broadcast_to(mass_v[None, :], phi.shape)
+    return phi - np.sum(phi * w) / np.sum(w)
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name))
+
+
+def random_state(s, seed):
+    rng = np.random.default_rng(seed)
+    for k in STATE:
+        setattr(s, k, rng.standard_normal(getattr(s, k).shape))
+    s.beta_fst[:, ::3] -= 6.0     # reach all three branches of the cone projection
+    s.beta_fst[:, 1::3] += 6.0
+
+
+def make_pair(g, lap_solver="spacetime_pcg", reorder=True, eps=0.0, congestion=0.0, seed=7):
+    from dots_socp_amd.device import DeviceProblem
+
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    T = int(g["n_time"])
+    s = O.OracleSolver(T, geom, congestion=congestion, eps=eps)
+    random_state(s, seed)
+    s.r, s.sz, s.d = 1.7, 2.5, 1.3
+    s.norm_d *= 1.3
+    s.bnd /= s.r
+    dev = DeviceProblem(T, geom, lap_solver=lap_solver, reorder=reorder)
+    for k in STATE:
+        dev.upload(k, getattr(s, k))
+    dev.set_params(r=s.r, scale_z=s.sz, const_d=s.d, norm_d=s.norm_d, congestion=congestion, eps=eps, tau=s.tau,
+                   cg_tol=1e-12, cg_max_iter=20000)
+    return s, dev
+
+
+@pytest.mark.parametrize("fname", OPS)
+@pytest.mark.parametrize("reorder", [False, True])
+def test_upload_download_roundtrip(fname, reorder):
+    s, dev = make_pair(golden(fname), reorder=reorder)
+    for k in STATE:
+        assert np.array_equal(dev.download(k), getattr(s, k)), k
+    dev.close()
+
+
+@pytest.mark.parametrize("fname", OPS)
+def test_soc_projection_a7(fname):
+    g = golden(fname)
+    s, dev = make_pair(g)
+    s.step_soc_projection()
+    dev.run_phase("soc_projection")
+    for k in ("z_fst", "z_mid", "z_end"):
+        assert rel(dev.download(k), getattr(s, k)) < FP_TOL, k
+    # and directly against the reference's recorded output for its own inputs
+    for k in ("A", "B", "beta_fst", "beta_mid", "beta_end"):
+        dev.upload(k, g[f"st_{k}"])
+    dev.set_params(scale_z=float(g["soc_scale_z"]), const_d=float(g["soc_const_d"]))
+    dev.run_phase("soc_projection")
+    for k in ("z_fst", "z_mid", "z_end"):
+        assert rel(dev.download(k), g[f"soc_{k}"]) < FP_TOL, k
+    dev.close()
+
+
+@pytest.mark.parametrize("fname", OPS)
+@pytest.mark.parametrize("congestion", [0.0, 0.1])
+def test_q_lambda_and_multipliers_a8_a9(fname, congestion):
+    s, dev = make_pair(golden(fname), congestion=congestion)
+    s.step_q_lambda()
+    s.step_multipliers()
+    dev.run_phase("q_lambda_mult")
+    for k in ("A", "B", "lambda_c", "mu", "E", "beta_fst", "beta_mid", "beta_end"):
+        assert rel(dev.download(k), getattr(s, k)) < FP_TOL, k
+    for k in ("phi", "z_fst", "z_mid", "z_end"):
+        assert np.array_equal(dev.download(k), getattr(s, k)), k
+    dev.close()
+
+
+@pytest.mark.parametrize("fname", OPS)
+@pytest.mark.parametrize("lap_solver", ["spacetime_pcg", "modal_pcg"])
+@pytest.mark.parametrize("eps", [0.0, 1e-2])
+def test_laplacian_step_a2_a3(fname, lap_solver, eps):
+    g = golden(fname)
+    s, dev = make_pair(g, lap_solver=lap_solver, eps=eps)
+    s.step_laplacian()
+    st = dev.run_phase("laplacian")
+    assert st.cg_not_converged == 0 and st.cg_last_iterations > 0
+    got, want = dev.download("phi"), s.phi
+    if eps == 0.0:
+        got, want = remove_gauge(got, s.mass_v), remove_gauge(want, s.mass_v)
+    assert rel(got, want) < 1e-9, (st.cg_last_iterations, st.cg_last_rel_residual)
+    dev.close()
+
+
+@pytest.mark.parametrize("fname", OPS)
+def test_laplacian_matches_reference_vector(fname):
+    g = golden(fname)
+    for tag in ("eps0", "eps1"):
+        eps = float(g[f"lap_{tag}_eps"])
+        s, dev = make_pair(g, eps=eps)
+        for k in ("A", "B", "lambda_c", "mu", "E"):
+            dev.upload(k, g[f"st_{k}"])
+        dev.upload("phi", g["q_phi"])
+        dev.set_params(r=float(g["q_r"]))
+        dev.run_phase("laplacian")
+        got, want = dev.download("phi"), g[f"lap_{tag}_phi"]
+        if eps == 0.0:
+            got, want = remove_gauge(got, s.mass_v), remove_gauge(want, s.mass_v)
+        assert rel(got, want) < 1e-9
+        dev.close()
+
+
+@pytest.mark.parametrize("fname", OPS)
+def test_operators_a4_a5_a6(fname):
+    g = golden(fname)
+    s, dev = make_pair(g, eps=1e-2)
+    assert rel(dev.apply_operator("grad_time", g["x_c"]), g["grad_time"]) < FP_TOL
+    assert rel(dev.apply_operator("div_time", g["x_t"]), g["div_time"]) < FP_TOL
+    assert rel(dev.apply_operator("grad_space", g["x_c"]), g["grad_space"]) < FP_TOL
+    assert rel(dev.apply_operator("div_space", g["x_s"]), g["div_space"]) < FP_TOL
+    assert rel(dev.apply_operator("decouple", g["x_s"], 1.7), g["decouple"]) < FP_TOL
+    assert rel(dev.apply_operator("decouple_adjoint", g["x_d"], 1.7), g["decouple_adjoint"]) < FP_TOL
+    assert rel(dev.apply_operator("time_avg_adjoint", g["x_t"]), g["decouple_adjoint_time"]) < FP_TOL
+    # K x against the assembled N x N space-time CSR of the oracle (sign: K = -Laplacian + eps M)
+    K = -O.assemble_spacetime_laplacian(s.T, s.h, s.mass_v, s.L, 1e-2)
+    want = K.dot(g["x_c"].reshape(-1)).reshape(g["x_c"].shape)
+    assert rel(dev.apply_operator("laplacian_apply", g["x_c"]), want) < 1e-11
+    dev.close()
+
+
+@pytest.mark.parametrize("fname", OPS)
+@pytest.mark.parametrize("congestion", [0.0, 0.15])
+def test_kkt_objective_norms_a10_a11_a12(fname, congestion):
+    s, dev = make_pair(golden(fname), congestion=congestion)
+    # state after a step so that dt_phi / dx_phi / dec_B are the ones the closures see
+    s.step_q_lambda()
+    s.step_multipliers()
+    dev.run_phase("q_lambda_mult")
+    want = [f() for f in s.kkt_functions()]
+    got = dev.kkt(range(7))
+    for i in range(7):
+        assert abs(got[i][0] - want[i][0]) <= 1e-11 * abs(want[i][0]), i
+        if i < 4:
+            assert abs(got[i][1] - want[i][1]) <= 1e-11 * abs(want[i][1]), i
+        else:
+            assert got[i][1] is None
+    # single conditions evaluated lazily give the same numbers
+    for i in range(7):
+        one = dev.kkt([i])
+        assert one[i][0] == pytest.approx(got[i][0], rel=1e-14, abs=0.0)
+    cost, obj = dev.objective()
+    wc, wo = s.objective()
+    assert abs(cost - wc) < 1e-12 * abs(wc) and abs(obj - wo) < 1e-12 * abs(wo)
+    assert dev.norm_square("mu") == pytest.approx(s.nsq_time(s.mu), rel=1e-13)
+    assert dev.norm_square("phi") == pytest.approx(s.nsq_center(s.phi), rel=1e-13)
+    assert dev.norm_square("phi", 1) == pytest.approx(s.nsq_time(s.dt_phi), rel=1e-12)
+    assert dev.norm_square("phi", 2) == pytest.approx(s.nsq_space(s.dx_phi), rel=1e-12)
+    assert dev.norm_square("E") == pytest.approx(s.nsq_space(s.E), rel=1e-13)
+    assert dev.norm_square("beta_mid") == pytest.approx(s.nsq_space_dec(s.beta_mid), rel=1e-13)
+    dev.close()
+
+
+@pytest.mark.parametrize("fname", OPS[:1])
+def test_scaling_tools_a13(fname):
+    s, dev = make_pair(golden(fname))
+    s.adjust_penalty(1.35)
+    dev.adjust_penalty(1.35)
+    dev.set_params(r=s.r)
+    for k in ("mu", "E", "beta_fst", "beta_mid", "beta_end"):
+        assert rel(dev.download(k), getattr(s, k)) < 1e-15, k
+    sz_old = s.sz
+    s.scale_z(1.6)
+    dev.scale_z(s.sz, 1.0 / s.sz, s.sz)
+    assert s.sz == pytest.approx(sz_old * 1.6)
+    for k in STATE:
+        assert rel(dev.download(k), getattr(s, k)) < 1e-14, k
+    dev.close()
+
+
+def test_full_iterations_track_oracle():
+    """20 complete ALM iterations from the reference's start state stay on the oracle's trajectory."""
+    from dots_socp_amd.device import DeviceProblem
+
+    g = golden("ops_ico1.npz")
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    T = int(g["n_time"])
+    for lap in ("spacetime_pcg", "modal_pcg"):
+        s = O.OracleSolver(T, geom)
+        s.scale_z(2.0)
+        dev = DeviceProblem(T, geom, lap_solver=lap)
+        dev.scale_z(2.0, 0.5, 2.0)
+        dev.set_params(scale_z=2.0, const_d=2.0, norm_d=s.norm_d, cg_tol=1e-11)
+        for _ in range(20):
+            s.iterate()
+        st = dev.step(20)
+        assert st.alm_iterations == 20 and st.cg_not_converged == 0
+        for k in ("A", "B", "mu", "E", "z_mid", "beta_mid"):
+            assert rel(dev.download(k), getattr(s, k)) < 1e-8, (lap, k)
+        want = s.kkt_all()
+        got = dev.kkt(range(7))
+        for i in range(7):
+            assert abs(got[i][0] - want[i]) <= 1e-7 * abs(want[i]) + 1e-14, (lap, i)
+        dev.close()

@@ -1,0 +1,123 @@
+"""GPU parity of the whole solver against the reference's recorded runs (tests/golden/run_*.npz):
+same stopping iteration, same lazy-KKT pattern, KKT values, cost and solution arrays."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, load_oracle
+
+pytestmark = pytest.mark.gpu
+
+O = load_oracle()
+RUNS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN_DIR, "run_*.npz")))
+SMALL = [r for r in RUNS if "refplane20" not in r]
+HEADLINE = [r for r in RUNS if "refplane20" in r]
+REL_TOL = 1e-6     # BASELINE.json north_star: cost and KKT residuals within 1e-6 relative of the reference
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name))
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def run_hip(g, **extra):
+    from dots_socp_amd.socp import solver_socp
+
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    kw = {}
+    for k in g.files:
+        if k.startswith("kw_"):
+            val = g[k]
+            kw[k[3:]] = val.tolist() if val.ndim else val.item()
+    kw.update(extra)
+    return solver_socp(int(g["n_time"]), geom, **kw)
+
+
+def mass_of(g):
+    area = O.triangle_quantities(g["vertices"], g["triangles"])[0]
+    return O.corner_maps(g["vertices"].shape[0], g["triangles"], area)[1] / 3.0
+
+
+def remove_gauge(phi, mass_v):
+    w = np.broadcast_to(mass_v[None, :], phi.shape)
+    return phi - np.sum(phi * w) / np.sum(w)
+
+
+def compare(g, sol, hist, rtol):
+    assert int(hist.kkt_iteration[-1]) == int(g["last_iteration"])
+    want, got = g["hist_kkt_errors"], hist.kkt_errors
+    assert got.shape == want.shape
+    assert np.array_equal(np.isnan(got), np.isnan(want)), "lazy KKT schedule differs from the reference"
+    m = ~np.isnan(want)
+    assert np.allclose(got[m], want[m], rtol=rtol, atol=1e-13)
+    for key in ("Transportation cost", "Objective value"):
+        w = g["hist_" + key.replace(" ", "_")]
+        assert np.allclose(hist.history[key], w, rtol=rtol, atol=0, equal_nan=True), key
+    eps = float(g["kw_eps"]) if "kw_eps" in g.files else 0.0
+    for k in g.files:
+        if not k.startswith("sol_"):
+            continue
+        a, b = sol[k[4:]], g[k]
+        if k == "sol_phi" and eps == 0.0:
+            a, b = remove_gauge(a, mass_of(g)), remove_gauge(b, mass_of(g))
+        assert rel(a, b) < 50 * rtol, k
+
+
+@pytest.mark.parametrize("fname", SMALL)
+@pytest.mark.parametrize("lap_solver", ["modal_pcg", "spacetime_pcg"])
+def test_runs_match_reference(fname, lap_solver):
+    g = golden(fname)
+    sol, hist = run_hip(g, lap_solver=lap_solver, cg_tol=1e-11)
+    assert hist.solver_stats["cg_not_converged"] == 0
+    compare(g, sol, hist, REL_TOL)
+    if "ckpt_iteration" in g.files:
+        assert [c["iteration"] for c in sol["checkpoints"]] == g["ckpt_iteration"].tolist()
+        assert rel(np.stack([c["mu"] for c in sol["checkpoints"]]), g["ckpt_mu"]) < 1e-5
+
+
+@pytest.mark.parametrize("fname", HEADLINE)
+def test_headline_runs(fname):
+    """plane n=20, T=31, tol=1e-3: iteration index 361 / cost 4.00756e-2
+    (113 / 4.15684e-1 with congestion 0.1), reproduced on the GPU with the default solver settings."""
+    g = golden(fname)
+    sol, hist = run_hip(g)
+    compare(g, sol, hist, REL_TOL)
+    cost = hist.history["Transportation cost"][-1] / float(g["scale_factor"]) ** 2
+    want = 4.156843973748015e-01 if "cong" in fname else 4.007560699483875e-02
+    assert abs(cost - want) < REL_TOL * want
+
+
+def test_decorators_and_argument_errors():
+    from dots_socp_amd.socp import solver, solver_raw
+
+    g = golden("run_refplane4_T8_tol1e-3.npz")
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    raw, hist = solver_raw(8, geom, nit=30, tol=1e-3)
+    cen, _ = solver(8, geom, nit=30, tol=1e-3)
+    assert raw["mu"].shape == (8, geom["vertices"].shape[0]) and cen["mu"].shape == (9, geom["vertices"].shape[0])
+    assert np.allclose(cen["mu"][0], g["mu0"]) and np.allclose(cen["mu"][-1], g["mu1"])
+    assert np.allclose(cen["mu"][1:-1], 0.5 * (raw["mu"][:-1] + raw["mu"][1:]))
+    # masses: every time slice of the staggered solution carries total mass ~ 1 once converged enough
+    assert "Transportation cost" in hist.history
+    for bad in ([], [2.0], "x", [1e-9]):
+        with pytest.raises(ValueError):
+            solver_raw(8, geom, nit=1, tol=1e-3, tol_checkpoints=bad)
+
+
+def test_warm_start_is_a_fixed_point():
+    """Restarting from a converged solution (init_solution, solver_socp.py:239-250) stops at once."""
+    from dots_socp_amd.socp import solver_socp
+
+    g = golden("run_refplane4_T8_tol1e-3.npz")
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    sol, hist = solver_socp(8, geom, nit=3000, tol=1e-3, is_z_scaling=False)
+    n1 = int(hist.kkt_iteration[-1])
+    init = {k: v for k, v in sol.items() if k != "checkpoints"}
+    sol2, hist2 = solver_socp(8, geom, nit=3000, tol=1e-3, is_z_scaling=False, init_solution=init)
+    assert int(hist2.kkt_iteration[-1]) < max(5, n1 // 10)
+    assert abs(hist2.history["Transportation cost"][-1] - hist.history["Transportation cost"][-1]) < 1e-3
