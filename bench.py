@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py -- ALM iterations per second of the DOTs-SOCP hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sphere10k|knot|torus100k|plane20]
+
+One "step" is one full pass of the solver's main loop (reference solver_socp.py:656-823): steps 1-3
+(Laplacian solve to the parity tolerance, cone projection, (q, lambda) + multiplier update) plus
+whatever KKT evaluation / penalty update the lazy schedule puts on that iteration.  All state is
+resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line.
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the T+1 time nodes are sharded in
+slabs; see dots-socp_amd/distributed.py.  `value` is whole-job iterations/s (the iterations are
+collective: every rank advances the same ALM iteration).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: "sphere mesh ~10k vertices, ntime=31, 1xMI355X, congestion=0.0"
+    "sphere10k": dict(example="sphere", kw=dict(level=5), n_time=31, congestion=0.0, tol=1e-3),
+    # configs[0] stand-in: knots_5-like tube, ntime=31
+    "knot": dict(example="knot", kw={}, n_time=31, congestion=0.0, tol=1e-3),
+    # configs[3]: ~100k-vertex torus, ntime=31
+    "torus100k": dict(example="torus", kw=dict(nu=400, nv=250), n_time=31, congestion=0.0, tol=1e-3),
+    # the survey's analytic case
+    "plane20": dict(example="plane", kw=dict(n=20), n_time=31, congestion=0.0, tol=1e-3),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="sphere10k", choices=sorted(WORKLOADS))
+    ap.add_argument("--lap-solver", default="modal_pcg", choices=["modal_pcg", "spacetime_pcg"])
+    ap.add_argument("--cg-tol", type=float, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-time-to-tol", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(geom, n_time, congestion, budget_s):
+    """Time the CPU oracle (numpy + SuperLU restatement of the reference) on the same workload.
+
+    Bounded sample: operator setup is excluded (as for the GPU), then as many ALM iterations as
+    fit in ~budget_s seconds (at least 2)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("dots_oracle", os.path.join(ROOT, "oracle", "dots_oracle.py"))
+    O = importlib.util.module_from_spec(spec)
+    sys.modules["dots_oracle"] = O
+    spec.loader.exec_module(O)
+    import contextlib
+
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limit = threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        limit = contextlib.nullcontext()
+    with limit:
+        t0 = time.perf_counter()
+        s = O.OracleSolver(n_time, geom, congestion=congestion)
+        s.scale_z(2.0)
+        setup = time.perf_counter() - t0
+        s.iterate()   # warm caches
+        n, t0 = 0, time.perf_counter()
+        while True:
+            s.iterate()
+            n += 1
+            el = time.perf_counter() - t0
+            if (el > budget_s and n >= 2) or n >= 400:
+                break
+    return {
+        "value": n / el, "unit": "ALM iterations/s", "cores": 1, "kind": "port",
+        "sample": f"{n} ALM iterations of the numpy/SuperLU oracle after setup ({setup:.1f} s setup excluded), "
+                  f"1 BLAS thread, host {os.cpu_count()} logical CPUs",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+
+    from dots_socp_amd import meshes
+    from dots_socp_amd.socp.solver_socp import AlmSolver, DEFAULT_CG_TOL
+
+    wl = WORKLOADS[args.workload]
+    geom, _scale = meshes.example(wl["example"], **wl["kw"])
+    n_time, congestion, tol = wl["n_time"], wl["congestion"], wl["tol"]
+    cg_tol = args.cg_tol if args.cg_tol is not None else DEFAULT_CG_TOL
+    V, F = geom["vertices"].shape[0], geom["triangles"].shape[0]
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        from dots_socp_amd.distributed import ShardedAlmSolver
+
+        alm = ShardedAlmSolver(n_time, geom, congestion=congestion, nit=args.warmup + args.steps + 8, tol=1e-30,
+                               cg_tol=cg_tol, device=local_rank)
+    else:
+        alm = AlmSolver(n_time, geom, congestion=congestion, nit=args.warmup + args.steps + 8, tol=1e-30,
+                        lap_solver=args.lap_solver, cg_tol=cg_tol, device=local_rank)
+
+    def barrier():
+        alm.dev.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        alm.iterate()
+    barrier()
+    cg0 = alm.cg_total
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        alm.iterate()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    cg_per_it = (alm.cg_total - cg0) / max(args.steps, 1)
+    steps_time = dict(alm.run_history.steps_time)
+
+    # ---- roofline of the dominant kernel (PCG operator application), measured with hipEvents on the
+    # context's own stream in the state the timed region left behind
+    ms_apply, bytes_apply = alm.dev.bench_kernel(which=0, reps=200)
+    ms_update, bytes_update = alm.dev.bench_kernel(which=1, reps=200)
+    achieved = bytes_apply / (ms_apply * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "k_cg_apply (fused direction update + K p + p.Kp partials)",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "ms_per_launch": ms_apply, "algorithmic_bytes_per_launch": bytes_apply,
+        "second_kernel": {"kernel": "k_cg_update", "ms_per_launch": ms_update,
+                          "achieved": bytes_update / (ms_update * 1e-3) / 1e9, "algorithmic_bytes_per_launch": bytes_update},
+        "working_set_note": "CG working set fits the 256 MiB Infinity Cache at this size" if V * (n_time + 1) * 8 * 6 < 256e6 else "",
+    }
+    dev_bytes = alm.dev.device_bytes()
+    alm.close()
+
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_time_to_tol:
+        t1 = time.perf_counter()
+        solver = AlmSolver(n_time, geom, congestion=congestion, nit=20000, tol=tol, lap_solver=args.lap_solver, cg_tol=cg_tol,
+                           device=local_rank)
+        setup_s = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        while not solver.iterate():
+            pass
+        _, hist = solver.finalize(download=False)
+        solve_s = time.perf_counter() - t1
+        solver.close()
+        extra["time_to_tol"] = {
+            "tol": tol, "seconds": solve_s, "setup_seconds": setup_s, "iterations": int(hist.kkt_iteration[-1]) + 1,
+            "transport_cost": float(hist.history["Transportation cost"][-1]),
+            "max_kkt": float(max(hist.kkt_errors[-1])), "pcg_iterations": hist.solver_stats["cg_iterations"],
+        }
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    line = {
+        "metric": "ALM iterations/s", "value": args.steps / elapsed, "unit": "iterations/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {wl['example']} mesh V={V} F={F}, ntime={n_time}, congestion={congestion}, "
+                        f"cg_tol={cg_tol:g}, lap_solver={args.lap_solver if world == 1 else 'modal_pcg (mode-sharded)'}",
+            "unknowns": V * (n_time + 1), "state_bytes": 8 * ((n_time + 1) * V + 7 * n_time * V + 6 * (n_time + 1) * F + 36 * n_time * F),
+            "device_bytes": dev_bytes, "pcg_iterations_per_step": cg_per_it,
+            "step_seconds": steps_time,
+        },
+        "roofline": roofline,
+    }
+    line.update(extra)
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(geom, n_time, congestion, args.cpu_seconds)
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,7 +26,7 @@ EXPORTS = [
     "dots_abi_version", "dots_last_error", "dots_create", "dots_destroy", "dots_set_params", "dots_get_params",
     "dots_sync", "dots_upload", "dots_download", "dots_array_count", "dots_step", "dots_run_phase", "dots_kkt",
     "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
-    "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes",
+    "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
 ]
 
 
@@ -55,6 +55,21 @@ class Params(C.Structure):
         ("norm_boundary", C.c_double), ("congestion", C.c_double), ("tau", C.c_double), ("eps", C.c_double),
         ("prim_scale", C.c_double), ("dual_scale", C.c_double), ("boundary_scale", C.c_double), ("cg_tol", C.c_double),
         ("cg_max_iter", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class MgLevel(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("nnz", C.c_int32), ("rowptr", _i32p), ("col", _i32p), ("val_k", _f64p), ("val_m", _f64p),
+        ("diag_k", _f64p), ("diag_m", _f64p), ("n_coarse", C.c_int32), ("p_nnz", C.c_int32),
+        ("p_rowptr", _i32p), ("p_col", _i32p), ("p_val", _f64p), ("r_rowptr", _i32p), ("r_col", _i32p), ("r_val", _f64p),
+    ]
+
+
+class MgDesc(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_int32), ("n_cols", C.c_int32), ("omega", C.c_double),
+        ("levels", C.POINTER(MgLevel)), ("coarse_inverse", _f64p),
     ]
 
 
@@ -116,6 +131,8 @@ def load():
     lib.dots_norm_square.argtypes = [vp, C.c_int, C.c_int, _f64p]
     lib.dots_apply_operator.argtypes = [vp, C.c_int, C.c_double, _f64p, C.c_int64, _f64p, C.c_int64]
     lib.dots_bench_kernel.argtypes = [vp, C.c_int, C.c_int, _f64p, _f64p]
+    lib.dots_mg_setup.argtypes = [vp, C.POINTER(MgDesc)]
+    lib.dots_mg_enable.argtypes = [vp, C.c_int]
     lib.dots_device_bytes.argtypes = [vp]
     lib.dots_device_bytes.restype = C.c_int64
     for n in EXPORTS:

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -89,6 +90,7 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     d.n_vtiles = (d.V + d.VT - 1) / d.VT;
     d.n_ftiles = (3 * d.F + d.FT - 1) / d.FT;
     d.h = 1.0 / d.T;
+    d.cg_ncol = d.T + 1;
     c->nnz = p->lap_nnz;
     c->lap_solver = p->lap_solver;
 
@@ -150,7 +152,7 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     for (auto q : cgv)
         if ((rc = dev_alloc(c, q, nnode))) return rc;
     const int gv = xcd_grid(d.n_vtiles), gf = xcd_grid(d.n_ftiles);
-    const int64_t npart = std::max<int64_t>({(int64_t)MAX_SUMS * std::max(gv, gf) * 2, (int64_t)2 * (d.T + 1) * gv, 4096});
+    const int64_t npart = std::max<int64_t>({(int64_t)MAX_SUMS * std::max(gv, gf) * 2, cg_partials_needed(d), 4096});
     if ((rc = dev_alloc(c, &d.partials, npart))) return rc;
     if ((rc = dev_alloc(c, &d.scal, CgScalOffsets::TOTAL))) return rc;
     if ((rc = dev_alloc(c, &d.flags, FLAG_TOTAL))) return rc;
@@ -213,6 +215,29 @@ static int run_iteration(Ctx *c, dots_step_stats *st) {
     return 0;
 }
 
+static void mg_release(Ctx *c) {
+    for (int i = 0; i < c->n_mg_allocs; ++i) (void)hipFree(c->mg_allocs[i]);
+    c->n_mg_allocs = 0;
+    c->mg = MgDev{};
+}
+
+template <typename T>
+static int mg_upload(Ctx *c, const T **out, const T *host, int64_t count) {
+    void *p = nullptr;
+    const size_t bytes = sizeof(T) * (size_t)std::max<int64_t>(count, 1);
+    DOTS_HIP(hipMalloc(&p, bytes));
+    if (c->n_mg_allocs >= (int)(sizeof(c->mg_allocs) / sizeof(c->mg_allocs[0]))) {
+        (void)hipFree(p);
+        set_error("multigrid allocation table full");
+        return DOTS_ERR_STATE;
+    }
+    c->mg_allocs[c->n_mg_allocs++] = p;
+    if (host) DOTS_HIP(hipMemcpy(p, host, sizeof(T) * (size_t)count, hipMemcpyHostToDevice));
+    else DOTS_HIP(hipMemset(p, 0, bytes));
+    *out = (const T *)p;
+    return 0;
+}
+
 }  // namespace dots
 
 using namespace dots;
@@ -241,6 +266,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
     DOTS_HIP(hipSetDevice(desc->device));
     dots_ctx *c = new dots_ctx();
     c->device = desc->device;
+    if (const char *e = getenv("DOTS_CG_STAGE_LDS")) c->cg_stage_lds = atoi(e) != 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);
@@ -255,6 +281,7 @@ int dots_destroy(dots_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->cg_graph) (void)hipGraphExecDestroy(c->cg_graph);
+    for (int i = 0; i < c->n_mg_allocs; ++i) (void)hipFree(c->mg_allocs[i]);
     for (int i = 0; i < c->n_allocs; ++i) (void)hipFree(c->allocs[i]);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
@@ -429,6 +456,83 @@ int dots_apply_operator(dots_ctx *c, int op, double scale, const double *in, int
     if (rc) return rc;
     DOTS_HIP(e1);
     DOTS_HIP(e2);
+    return 0;
+}
+
+int dots_mg_setup(dots_ctx *c, const dots_mg_desc *m) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (!m || m->n_levels < 2 || m->n_levels > 10 || !m->levels || !m->coarse_inverse) { set_error("mg_setup: bad description"); return DOTS_ERR_ARGUMENT; }
+    if (c->lap_solver != DOTS_LAP_MODAL_PCG) { set_error("multigrid needs the modal solver"); return DOTS_ERR_ARGUMENT; }
+    if (m->levels[0].n != c->d.V || m->n_cols != c->d.cg_ncol) { set_error("mg_setup: level 0 / mode count mismatch"); return DOTS_ERR_ARGUMENT; }
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    if (c->cg_graph) { (void)hipGraphExecDestroy(c->cg_graph); c->cg_graph = nullptr; }
+    mg_release(c);
+    const Dev &d = c->d;
+    MgDev g{};
+    g.nlev = m->n_levels;
+    g.omega = m->omega;
+    for (int l = 0; l < m->n_levels; ++l) {
+        const dots_mg_level &h = m->levels[l];
+        MgLevelDev &L = g.lv[l];
+        L.n = h.n;
+        L.nc = h.n_coarse;
+        if (l + 1 < m->n_levels && (h.n_coarse != m->levels[l + 1].n || !h.p_rowptr || !h.r_rowptr)) { set_error("mg_setup: inconsistent level sizes"); mg_release(c); return DOTS_ERR_ARGUMENT; }
+        // index sanity (a wrong index would fault on the device)
+        if (l > 0) {
+            if (!h.rowptr || !h.col || !h.val_k || !h.val_m || !h.diag_k || !h.diag_m) { set_error("mg_setup: null level array"); mg_release(c); return DOTS_ERR_ARGUMENT; }
+            for (int j = 0; j < h.nnz; ++j) if (h.col[j] < 0 || h.col[j] >= h.n) { set_error("mg_setup: column index out of range"); mg_release(c); return DOTS_ERR_ARGUMENT; }
+            if (h.rowptr[h.n] != h.nnz) { set_error("mg_setup: rowptr/nnz mismatch"); mg_release(c); return DOTS_ERR_ARGUMENT; }
+        }
+        if (l + 1 < m->n_levels) {
+            if (h.p_rowptr[h.n] != h.p_nnz || h.r_rowptr[h.n_coarse] != h.p_nnz) { set_error("mg_setup: P/R size mismatch"); mg_release(c); return DOTS_ERR_ARGUMENT; }
+            for (int j = 0; j < h.p_nnz; ++j)
+                if (h.p_col[j] < 0 || h.p_col[j] >= h.n_coarse || h.r_col[j] < 0 || h.r_col[j] >= h.n) { set_error("mg_setup: P/R index out of range"); mg_release(c); return DOTS_ERR_ARGUMENT; }
+        }
+#define MUP(field, src, n) if ((rc = mg_upload(c, &L.field, src, (int64_t)(n)))) { mg_release(c); return rc; }
+        if (l == 0) {
+            L.rp = d.rowptr; L.col = d.col; L.vK = d.val; L.vM = nullptr; L.dK = d.kdiag; L.dM = d.mass_v;
+        } else {
+            MUP(rp, h.rowptr, h.n + 1); MUP(col, h.col, h.nnz); MUP(vK, h.val_k, h.nnz); MUP(vM, h.val_m, h.nnz);
+            MUP(dK, h.diag_k, h.n); MUP(dM, h.diag_m, h.n);
+        }
+        if (l + 1 < m->n_levels) {
+            MUP(p_rp, h.p_rowptr, h.n + 1); MUP(p_col, h.p_col, h.p_nnz); MUP(p_val, h.p_val, h.p_nnz);
+            MUP(r_rp, h.r_rowptr, h.n_coarse + 1); MUP(r_col, h.r_col, h.p_nnz); MUP(r_val, h.r_val, h.p_nnz);
+        }
+#undef MUP
+        const int64_t nv = (int64_t)h.n << d.tp_shift;
+        const double *tmp = nullptr;
+        if (l == 0) {
+            L.x = d.cg_Ap;   // free between k_cg_update and the next k_cg_apply
+            if ((rc = mg_upload<double>(c, &tmp, nullptr, nv))) { mg_release(c); return rc; }
+            L.r = const_cast<double *>(tmp);
+        } else {
+            double **vecs[4] = {&L.b, &L.x, &L.x2, &L.r};
+            for (auto v : vecs) {
+                if ((rc = mg_upload<double>(c, &tmp, nullptr, nv))) { mg_release(c); return rc; }
+                *v = const_cast<double *>(tmp);
+            }
+        }
+    }
+    // coarse inverse: host [nL][nL][n_cols] -> device [nL][nL][TP]
+    const int nL = m->levels[m->n_levels - 1].n;
+    std::vector<double> inv((size_t)nL * nL * d.TP, 0.0);
+    for (int64_t ij = 0; ij < (int64_t)nL * nL; ++ij)
+        for (int k = 0; k < m->n_cols; ++k) inv[(size_t)ij * d.TP + k] = m->coarse_inverse[(size_t)ij * m->n_cols + k];
+    if ((rc = mg_upload(c, &g.coarse_inv, inv.data(), (int64_t)inv.size()))) { mg_release(c); return rc; }
+    // mg_release() reset c->mg; the level pointers were written into the local copy
+    for (int l = 0; l < g.nlev; ++l) c->mg.lv[l] = g.lv[l];
+    c->mg.nlev = g.nlev;
+    c->mg.omega = g.omega;
+    c->mg.coarse_inv = g.coarse_inv;
+    return 0;
+}
+
+int dots_mg_enable(dots_ctx *c, int on) {
+    int rc = check(c);
+    if (rc) return rc;
+    c->use_mg = on ? 1 : 0;
     return 0;
 }
 

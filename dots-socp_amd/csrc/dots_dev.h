@@ -65,6 +65,26 @@ struct Dev {
     double *partials;        // [MAX_SUMS or NC][n partial blocks]
     double *scal;            // device scalars, see CgScal / sums
     int *flags;
+    int cg_ncol;             // columns the PCG works on (T+1 on one GPU; the rank's modes when sharded)
+};
+
+// One level of the multigrid hierarchy (device pointers).  A_l = K_l + s M_l on one pattern;
+// level 0 has vM == nullptr (M is the diagonal mass, held in dM).
+struct MgLevelDev {
+    int n, nc;                               // rows of this level / of the next coarser one
+    const int *rp, *col;
+    const double *vK, *vM, *dK, *dM;
+    const int *p_rp, *p_col;                 // P: n x nc
+    const double *p_val;
+    const int *r_rp, *r_col;                 // R = P^T: nc x n
+    const double *r_val;
+    double *b, *x, *x2, *r;                  // level vectors [n][TP]
+};
+struct MgDev {
+    int nlev = 0;
+    MgLevelDev lv[10]{};
+    const double *coarse_inv = nullptr;      // [nL][nL][TP]
+    double omega = 2.0 / 3.0;
 };
 
 // Layout of the device scalar block used by the PCG (all arrays have NC entries, NC <= 256).
@@ -98,6 +118,8 @@ int launch_operator(Ctx *c, int op, double scale, const double *in_staged, doubl
 int cg_solve(Ctx *c, dots_step_stats *stats);
 int cg_apply_operator(Ctx *c, const double *x_node, double *y_node);  // y = K x in node layout
 int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes);
+int64_t cg_partials_needed(const Dev &d);   // doubles of Dev::partials the PCG uses
+int mg_vcycle(Ctx *c, const double *r, double *z, double *rz_part, int ept, int vt, int G);  // enqueue z = MG(r)
 int kkt_evaluate(Ctx *c, uint32_t mask, double *out);
 int objective_evaluate(Ctx *c, double *out);
 int norm_square(Ctx *c, int array_id, int part, double *out);
@@ -118,6 +140,12 @@ struct Ctx {
     int *h_flags = nullptr;
     int n_partial_blocks = 0;
     int last_cg_iters = 0;
+    int cg_stage_lds = 1;         // stage CSR row blocks in LDS (DOTS_CG_STAGE_LDS=0 disables, for A/B measurements)
+    MgDev mg{};                   // multigrid preconditioner (nlev == 0: Jacobi only)
+    int use_mg = 1;
+    int cg_graph_mg = -1;
+    void *mg_allocs[160]{};
+    int n_mg_allocs = 0;
     // constants of the KKT normalisation (solver_socp.py:303-313)
     double c_prim_q = 0, c_prim_z = 0, c_dual_alpha = 0, c_dual_beta = 0, c_comp_rho = 0, c_comp_m = 0;
     void *allocs[64]{};

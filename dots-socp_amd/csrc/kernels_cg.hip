@@ -1,4 +1,4 @@
-// Jacobi-preconditioned CG for the space-time Laplacian of step 1 (replaces the reference's
+// Preconditioned CG for the space-time Laplacian of step 1 (replaces the reference's
 // eigen-decomposition + SuperLU solve, utils/laplacian_inverse_socp.py:11-61).
 //
 // Operator.  K = -(L_time (x) M + I (x) L_space) + eps I (x) M, with L_space the cotangent
@@ -11,231 +11,355 @@
 // its block of rows in LDS (coalesced load, then broadcast reads).
 //
 // Two solvers share the kernels (template MODAL):
-//   SPACETIME  one PCG on the coupled operator, one set of scalars (alpha, beta, ...).
+//   SPACETIME  one Jacobi-PCG on the coupled operator, one set of scalars.
 //   MODAL      the orthonormal time eigen-basis Q (DCT-II) block-diagonalises K into T+1 shifted
 //              surface problems K_space + (sigma_a + eps) M; they are solved as one batched PCG with
-//              per-column scalars; converged columns are frozen and skipped.
+//              per-column scalars; converged columns are frozen and skipped.  Preconditioner: Jacobi,
+//              or the multigrid V-cycle of kernels_mg.hip when a hierarchy has been uploaded.
 //
-// Reductions are two-stage and deterministic: workgroups write partial sums, a one-workgroup-per-column
-// kernel adds them in a fixed order and updates the scalars on device.  Nothing returns to the host
-// inside an iteration; the host polls the `done` flags between chunks of iterations.
+// One Jacobi-PCG iteration is TWO kernels and no host round trip:
+//   k_cg_apply   beta from the r.z partial sums of the previous kernel; p = z + beta p_old formed on the
+//                fly at every gathered entry; writes p, Ap; emits partial sums of p.Ap
+//   k_cg_update  alpha from the p.Ap partial sums; x += alpha p, r -= alpha Ap, z = D^-1 r; emits r.z
+// (with multigrid the V-cycle kernels run between the two and the last of them emits r.z).
+// Every workgroup re-reduces the (few hundred) per-workgroup partial sums of the kernel before it, in
+// the same fixed order, so all workgroups see bit-identical scalars: no atomics, no separate reduction
+// kernels, deterministic results.  Scalars that outlive a kernel (r.z totals, done flags, iteration
+// counter) are written by workgroup 0 only, into the buffer of the current parity; readers of the
+// same launch use the other parity.  The loop body is captured once in a hipGraph; the host polls
+// the done flags between replays.
+// Stopping rule (both preconditioners): r^T D^-1 r <= cg_tol^2 * b^T D^-1 b with D = diag(K).
 #include "dots_dev.h"
+
+#include <vector>
 
 namespace dots {
 
 using S = CgScalOffsets;
+constexpr int CG_NB = 1024;          // threads per workgroup of the PCG kernels (16 wave64)
 
 template <bool MODAL>
 __device__ __forceinline__ double shift_of(const Dev &d, int t) {
     if (MODAL) return d.sigma[t];
     return ((t == 0 || t == d.T) ? 1.0 : 2.0) / (d.h * d.h);
 }
-
-// true when every column has converged (uniform over the workgroup)
 template <bool MODAL>
-__device__ __forceinline__ bool all_done(const Dev &d) {
-    if (!MODAL) return d.flags[0] != 0;
-    const int nc = d.T + 1;
-    int mine = 1;
-    for (int c = threadIdx.x; c < nc; c += BLOCK) mine &= (d.flags[c] != 0);
-    return __syncthreads_and(mine) != 0;
+__device__ __forceinline__ int n_cols(const Dev &d) { return MODAL ? d.cg_ncol : d.T + 1; }
+
+// Dynamic LDS carve-up of the PCG kernels.
+struct CgLds {
+    double *val;    // [cap]   staged CSR values
+    double *red;    // [CG_NB] reduction scratch
+    double *tot;    // [CG_NB] column totals / broadcast
+    int *col;       // [cap]
+    int *rp;        // [VT + 2]
+};
+__device__ __forceinline__ CgLds carve(unsigned char *base, int cap) {
+    CgLds l;
+    l.val = reinterpret_cast<double *>(base);
+    l.red = l.val + cap;
+    l.tot = l.red + CG_NB;
+    l.col = reinterpret_cast<int *>(l.tot + CG_NB);
+    l.rp = l.col + cap;
+    return l;
+}
+static size_t cg_lds_bytes(int cap, int vt) { return sizeof(double) * ((size_t)cap + 2 * CG_NB) + sizeof(int) * ((size_t)cap + vt + 2); }
+
+// Sum over workgroups of a partial array part[G][TP] (column fastest: one coalesced row per workgroup)
+// for the column of the calling thread (MODAL: c = tid & (TP-1); otherwise the single column 0).
+template <bool MODAL>
+__device__ __forceinline__ double column_total(const Dev &d, const double *part, int G, const CgLds &l) {
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    if (MODAL) {
+        const int c = tid & (d.TP - 1), j = tid >> d.tp_shift, J = CG_NB >> d.tp_shift;
+        if (c < d.cg_ncol)
+            for (int g = j; g < G; g += J) s += part[((int64_t)g << d.tp_shift) + c];
+        l.red[tid] = s;
+        __syncthreads();
+        if (j == 0) {
+            double t = 0.0;
+            for (int k = 0; k < J; ++k) t += l.red[c + (k << d.tp_shift)];
+            l.tot[c] = t;
+        }
+        __syncthreads();
+        const double out = l.tot[c];
+        __syncthreads();
+        return out;
+    } else {
+        for (int g = tid; g < G; g += CG_NB) s += part[g];
+        s = wave_sum(s);
+        if ((tid & 63) == 0) l.red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int k = 0; k < CG_NB / 64; ++k) t += l.red[k];
+            l.tot[0] = t;
+        }
+        __syncthreads();
+        const double out = l.tot[0];
+        __syncthreads();
+        return out;
+    }
 }
 
-// per-column (MODAL) or whole-block sum of one value per thread -> partials[(slot*NC + c)*nblk + blk]
+// Emit the per-workgroup partial sum(s) of one value per thread into part[G][TP] (fixed order).
 template <bool MODAL>
-__device__ __forceinline__ void emit_partial(const Dev &d, double acc, int slot, double *lds /* [BLOCK] */) {
-    const int nblk = gridDim.x;
+__device__ __forceinline__ void emit_partial(const Dev &d, double acc, double *part, const CgLds &l) {
+    const int tid = threadIdx.x;
     if (MODAL) {
-        // all elements of a thread share the column (tid & (TP-1)); TP <= BLOCK is enforced at create
-        lds[threadIdx.x] = acc;
+        const int c = tid & (d.TP - 1), j = tid >> d.tp_shift, J = CG_NB >> d.tp_shift;
+        l.red[tid] = acc;
         __syncthreads();
-        const int nc = d.T + 1;
-        if ((int)threadIdx.x < d.TP) {
-            double s = 0.0;
-            for (int j = threadIdx.x; j < BLOCK; j += d.TP) s += lds[j];
-            if ((int)threadIdx.x < nc) d.partials[((int64_t)slot * nc + threadIdx.x) * nblk + blockIdx.x] = s;
+        if (j == 0 && c < d.cg_ncol) {
+            double t = 0.0;
+            for (int k = 0; k < J; ++k) t += l.red[c + (k << d.tp_shift)];
+            part[((int64_t)blockIdx.x << d.tp_shift) + c] = t;
         }
         __syncthreads();
     } else {
-        double v[1] = {acc};
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) d.partials[(int64_t)slot * nblk + blockIdx.x] = v[0];
+        double s = wave_sum(acc);
+        if ((tid & 63) == 0) l.red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int k = 0; k < CG_NB / 64; ++k) t += l.red[k];
+            part[blockIdx.x] = t;
+        }
         __syncthreads();
     }
 }
 
+struct CgArgs {
+    const double *zin;     // z (FUSE_P) or x (plain apply)
+    const double *p_old;
+    double *p_new;
+    double *out;           // Ap / y
+    double *x;
+    double eps, tol2;
+    int parity;            // which r.z buffer this iteration reads
+    int ept;               // elements per thread
+    int vt;                // vertices per tile = CG_NB * ept / TP
+    int cap;               // staged CSR capacity
+    int G;                 // workgroups (= tiles, padded to a multiple of 8)
+    int nc;                // scalar columns
+    int pstride;           // doubles per partial array = G * TP (MODAL) or G
+    int stage;             // 1: stage the CSR row block in LDS, 0: read it through L1
+    int mg;                // 1: z comes from the multigrid V-cycle (r.z and the stopping norm are separate sums)
+};
+
+// offsets into Dev::partials for the PCG: r.z (two parities), p.Ap, bref, stopping norm (two parities)
+__device__ __host__ __forceinline__ int64_t part_rz(const CgArgs &a, int parity) { return (int64_t)parity * a.pstride; }
+__device__ __host__ __forceinline__ int64_t part_pap(const CgArgs &a) { return (int64_t)2 * a.pstride; }
+__device__ __host__ __forceinline__ int64_t part_bref(const CgArgs &a) { return (int64_t)3 * a.pstride; }
+__device__ __host__ __forceinline__ int64_t part_crit(const CgArgs &a, int parity) {
+    return a.mg ? (int64_t)(4 + parity) * a.pstride : part_rz(a, parity);
+}
+constexpr int N_PART_ARRAYS = 6;
+constexpr int SC_RZ0 = S::RZ, SC_RZ1 = S::PAP;   // the two parities of the r.z totals
+
 // ------------------------------------------------------------------------------------------
 // Operator application with the CSR row block staged in LDS.
-//   FUSE_P = true : p_new = z + beta * p_old is formed on the fly at every gathered entry (so the
-//                   direction update costs no extra kernel), p_new and Ap = K p_new are written for the
-//                   tile's own rows, and the partial sums of p^T Ap are emitted.
-//   FUSE_P = false: plain y = K x (initial residual, tests, operator parity).
 // ------------------------------------------------------------------------------------------
 template <bool MODAL, bool FUSE_P>
-__global__ __launch_bounds__(BLOCK) void k_cg_apply(Dev d, const double *__restrict__ zin, const double *__restrict__ p_old,
-                                                    double *__restrict__ p_new, double *__restrict__ out, double eps,
-                                                    int check_done) {
-    __shared__ int s_rp[TILE_ELEMS / 8 + 2];
-    __shared__ int s_col[LDS_NNZ_CAP];
-    __shared__ double s_val[LDS_NNZ_CAP];
-    __shared__ double s_red[BLOCK];
-    if (check_done && all_done<MODAL>(d)) return;
+__global__ __launch_bounds__(CG_NB) void k_cg_apply(Dev d, CgArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const CgLds l = carve(lds_raw, a.cap);
+    const int tid = threadIdx.x;
+    const int col_of_thread = MODAL ? (tid & (d.TP - 1)) : 0;
+    const int ncols = n_cols<MODAL>(d);
 
-    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
-    double acc = 0.0;
-    if (tile < d.n_vtiles) {
-        const int v0 = tile * d.VT;
-        const int nrows = min(d.VT, d.V - v0);
-        const int rp0 = d.rowptr[v0];
-        for (int i = threadIdx.x; i <= nrows; i += BLOCK) s_rp[i] = d.rowptr[v0 + i] - rp0;
-        __syncthreads();
-        const int nloc = s_rp[nrows];
-        for (int i = threadIdx.x; i < min(nloc, LDS_NNZ_CAP); i += BLOCK) {
-            s_col[i] = d.col[rp0 + i];
-            s_val[i] = d.val[rp0 + i];
+    double beta = 0.0;
+    bool frozen = false;
+    if (FUSE_P) {
+        // scalars of this iteration, recomputed identically by every workgroup
+        const double rz_new = column_total<MODAL>(d, d.partials + part_rz(a, a.parity), a.G, l);
+        const double crit = a.mg ? column_total<MODAL>(d, d.partials + part_crit(a, a.parity), a.G, l) : rz_new;
+        const double rz_old = d.scal[(a.parity ? SC_RZ0 : SC_RZ1) + col_of_thread];
+        const double bref = d.scal[S::BREF + col_of_thread];
+        frozen = (d.flags[col_of_thread] != 0) || (crit <= a.tol2 * bref);
+        beta = (rz_old > 0.0) ? rz_new / rz_old : 0.0;
+        const bool col_valid = !MODAL || col_of_thread < ncols;
+        const int all = __syncthreads_and((!col_valid || frozen) ? 1 : 0);
+        if (blockIdx.x == 0) {
+            if (tid < a.nc) {   // tid == column for the first nc threads (MODAL: TP <= CG_NB; else nc == 1)
+                d.scal[(a.parity ? SC_RZ1 : SC_RZ0) + tid] = rz_new;
+                d.scal[S::ALPHA + tid] = crit;      // last stopping-norm value (diagnostics)
+                d.flags[tid] = frozen ? 1 : 0;
+            }
+            if (tid == 0 && !all) d.flags[FLAG_ITERS] += 1;
         }
-        __syncthreads();
+        if (all) return;
+    }
 
-        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+    const int tile = xcd_tile(blockIdx.x, a.G);
+    double acc = 0.0;
+    if (tile < a.G && tile * a.vt < d.V) {
+        const int v0 = tile * a.vt;
+        const int nrows = min(a.vt, d.V - v0);
+        const int rp0 = d.rowptr[v0];
+        const int cap = a.stage ? a.cap : 0;
+        if (a.stage) {
+            for (int i = tid; i <= nrows; i += CG_NB) l.rp[i] = d.rowptr[v0 + i] - rp0;
+            __syncthreads();
+            const int nloc = min(l.rp[nrows], cap);
+            for (int i = tid; i < nloc; i += CG_NB) {
+                l.col[i] = d.col[rp0 + i];
+                l.val[i] = d.val[rp0 + i];
+            }
+            __syncthreads();
+        }
+
+        const bool use_p = FUSE_P && (beta != 0.0);
+        for (int q = 0; q < a.ept; ++q) {
+            const int e = tid + q * CG_NB;
             const int vl = e >> d.tp_shift, t = e & (d.TP - 1);
+            if (vl >= nrows || t >= ncols) continue;
+            if (FUSE_P && MODAL && frozen) continue;
             const int v = v0 + vl;
-            if (vl >= nrows || t > d.T) continue;
-            const int cidx = MODAL ? t : 0;
-            if (FUSE_P && MODAL && d.flags[cidx]) continue;   // frozen column
-            const double beta = FUSE_P ? d.scal[S::BETA + cidx] : 0.0;
-            const bool use_p = FUSE_P && (beta != 0.0);
+            auto fetch = [&](int i) -> double {
+                double x = a.zin[i];
+                if (use_p) x += beta * a.p_old[i];
+                return x;
+            };
             double sum = 0.0;
-            for (int j = s_rp[vl]; j < s_rp[vl + 1]; ++j) {
-                const int u = (j < LDS_NNZ_CAP) ? s_col[j] : d.col[rp0 + j];
-                const double w = (j < LDS_NNZ_CAP) ? s_val[j] : d.val[rp0 + j];
-                const int iu = idxV(d, u, t);
-                double pu = zin[iu];
-                if (use_p) pu += beta * p_old[iu];
-                sum += w * pu;
+            int j = a.stage ? l.rp[vl] : d.rowptr[v] - rp0;
+            const int jend = a.stage ? l.rp[vl + 1] : d.rowptr[v + 1] - rp0;
+            // gathers in batches of four independent loads (rows have ~7 entries)
+            for (; j + 4 <= jend && j + 4 <= cap; j += 4) {
+                const int u0 = l.col[j], u1 = l.col[j + 1], u2 = l.col[j + 2], u3 = l.col[j + 3];
+                const double w0 = l.val[j], w1 = l.val[j + 1], w2 = l.val[j + 2], w3 = l.val[j + 3];
+                const double x0 = fetch(idxV(d, u0, t)), x1 = fetch(idxV(d, u1, t)), x2 = fetch(idxV(d, u2, t)),
+                             x3 = fetch(idxV(d, u3, t));
+                sum += (w0 * x0 + w1 * x1) + (w2 * x2 + w3 * x3);
+            }
+            for (; j + 4 <= jend; j += 4) {   // entries that are not staged: straight from global (L1 broadcast)
+                const int *cp = d.col + rp0 + j;
+                const double *vp = d.val + rp0 + j;
+                const int u0 = cp[0], u1 = cp[1], u2 = cp[2], u3 = cp[3];
+                const double x0 = fetch(idxV(d, u0, t)), x1 = fetch(idxV(d, u1, t)), x2 = fetch(idxV(d, u2, t)),
+                             x3 = fetch(idxV(d, u3, t));
+                sum += (vp[0] * x0 + vp[1] * x1) + (vp[2] * x2 + vp[3] * x3);
+            }
+            for (; j < jend; ++j) {
+                const int u = (j < cap) ? l.col[j] : d.col[rp0 + j];
+                const double w = (j < cap) ? l.val[j] : d.val[rp0 + j];
+                sum += w * fetch(idxV(d, u, t));
             }
             const int iv = idxV(d, v, t);
-            double pv = zin[iv];
-            if (use_p) pv += beta * p_old[iv];
+            const double pv = fetch(iv);
             const double m = d.mass_v[v];
             if (MODAL) {
-                sum += (d.sigma[t] + eps) * m * pv;
+                sum += (d.sigma[t] + a.eps) * m * pv;
             } else {
-                double pm = 0.0, pp = 0.0;
-                if (t > 0) {
-                    pm = zin[iv - 1];
-                    if (use_p) pm += beta * p_old[iv - 1];
-                }
-                if (t < d.T) {
-                    pp = zin[iv + 1];
-                    if (use_p) pp += beta * p_old[iv + 1];
-                }
+                const double pm = (t > 0) ? fetch(iv - 1) : 0.0;
+                const double pp = (t < d.T) ? fetch(iv + 1) : 0.0;
                 const double ct = (t == 0 || t == d.T) ? 1.0 : 2.0;
-                sum += m * ((ct * pv - pm - pp) / (d.h * d.h) + eps * pv);
+                sum += m * ((ct * pv - pm - pp) / (d.h * d.h) + a.eps * pv);
             }
-            out[iv] = sum;
+            a.out[iv] = sum;
             if (FUSE_P) {
-                p_new[iv] = pv;
+                a.p_new[iv] = pv;
                 acc += pv * sum;
             }
         }
     }
-    if (FUSE_P) emit_partial<MODAL>(d, acc, 0, s_red);
+    if (FUSE_P) emit_partial<MODAL>(d, acc, d.partials + part_pap(a), l);
 }
 
-// r = (b - bmean) - K x ;  z = M^-1 r ;  partial sums of r^T z (slot 0) and b~^T M^-1 b~ (slot 1)
+// r = (b - bmean) - K x ;  z = D^-1 r (Jacobi only) ;  partial sums of r^T D^-1 r (parity 0) and b~^T D^-1 b~
 template <bool MODAL>
-__global__ __launch_bounds__(BLOCK) void k_cg_r0(Dev d, const double *__restrict__ b, const double *__restrict__ Kx, double eps) {
-    __shared__ double s_red[BLOCK];
-    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+__global__ __launch_bounds__(CG_NB) void k_cg_r0(Dev d, CgArgs a, const double *__restrict__ b, const double *__restrict__ Kx) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const CgLds l = carve(lds_raw, a.cap);
+    const int tile = xcd_tile(blockIdx.x, a.G);
+    const int ncols = n_cols<MODAL>(d);
     double a0 = 0.0, a1 = 0.0;
-    if (tile < d.n_vtiles) {
-        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
-            const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-            if (v >= d.V || t > d.T) continue;
+    if (tile < a.G) {
+        for (int q = 0; q < a.ept; ++q) {
+            const int e = threadIdx.x + q * CG_NB;
+            const int v = tile * a.vt + (e >> d.tp_shift), t = e & (d.TP - 1);
+            if ((e >> d.tp_shift) >= a.vt || v >= d.V || t >= ncols) continue;
             const int iv = idxV(d, v, t);
             const int cidx = MODAL ? t : 0;
             const double bt = b[iv] - d.scal[S::BMEAN + cidx];
             const double r = bt - Kx[iv];
-            const double dinv = 1.0 / (d.kdiag[v] + (shift_of<MODAL>(d, t) + eps) * d.mass_v[v]);
+            const double dinv = 1.0 / (d.kdiag[v] + (shift_of<MODAL>(d, t) + a.eps) * d.mass_v[v]);
             const double z = dinv * r;
             d.cg_r[iv] = r;
-            d.cg_z[iv] = z;
+            if (!a.mg) d.cg_z[iv] = z;
             a0 += r * z;
             a1 += bt * dinv * bt;
         }
     }
-    emit_partial<MODAL>(d, a0, 0, s_red);
-    emit_partial<MODAL>(d, a1, 1, s_red);
+    emit_partial<MODAL>(d, a0, d.partials + part_crit(a, 0), l);
+    emit_partial<MODAL>(d, a1, d.partials + part_bref(a), l);
 }
 
-// x += alpha p ; r -= alpha Ap ; z = M^-1 r ; partial sums of r^T z
+// once per solve: bref totals, zero the r.z totals of both parities, clear flags and the counter
 template <bool MODAL>
-__global__ __launch_bounds__(BLOCK) void k_cg_update(Dev d, double *__restrict__ x, const double *__restrict__ p, double eps) {
-    __shared__ double s_red[BLOCK];
-    if (all_done<MODAL>(d)) return;
-    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+__global__ __launch_bounds__(CG_NB) void k_cg_begin(Dev d, CgArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const CgLds l = carve(lds_raw, a.cap);
+    const double bref = column_total<MODAL>(d, d.partials + part_bref(a), a.G, l);
+    const int tid = threadIdx.x;
+    if (tid < a.nc) {
+        d.scal[S::BREF + tid] = bref;
+        d.scal[SC_RZ0 + tid] = 0.0;
+        d.scal[SC_RZ1 + tid] = 0.0;
+        d.flags[tid] = 0;
+    }
+    if (tid == 0) d.flags[FLAG_ITERS] = 0;
+}
+
+// x += alpha p ; r -= alpha Ap ; z = D^-1 r (Jacobi) ; partial sums of r^T D^-1 r into the other parity
+template <bool MODAL>
+__global__ __launch_bounds__(CG_NB) void k_cg_update(Dev d, CgArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const CgLds l = carve(lds_raw, a.cap);
+    const int tid = threadIdx.x;
+    const int col_of_thread = MODAL ? (tid & (d.TP - 1)) : 0;
+    const int ncols = n_cols<MODAL>(d);
+    const double pap = column_total<MODAL>(d, d.partials + part_pap(a), a.G, l);
+    const bool frozen = d.flags[col_of_thread] != 0;
+    const bool col_valid = !MODAL || col_of_thread < ncols;
+    if (__syncthreads_and((!col_valid || frozen) ? 1 : 0)) return;
+    const double rz = d.scal[(a.parity ? SC_RZ1 : SC_RZ0) + col_of_thread];
+    const double alpha = (frozen || !(pap > 0.0)) ? 0.0 : rz / pap;
+
+    const int tile = xcd_tile(blockIdx.x, a.G);
     double acc = 0.0;
-    if (tile < d.n_vtiles) {
-        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
-            const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-            if (v >= d.V || t > d.T) continue;
-            const int cidx = MODAL ? t : 0;
-            if (MODAL && d.flags[cidx]) continue;
+    if (tile < a.G) {
+        for (int q = 0; q < a.ept; ++q) {
+            const int e = tid + q * CG_NB;
+            const int v = tile * a.vt + (e >> d.tp_shift), t = e & (d.TP - 1);
+            if ((e >> d.tp_shift) >= a.vt || v >= d.V || t >= ncols) continue;
             const int iv = idxV(d, v, t);
-            const double alpha = d.scal[S::ALPHA + cidx];
-            x[iv] += alpha * p[iv];
-            const double r = d.cg_r[iv] - alpha * d.cg_Ap[iv];
-            const double z = r / (d.kdiag[v] + (shift_of<MODAL>(d, t) + eps) * d.mass_v[v]);
+            const double dinv = 1.0 / (d.kdiag[v] + (shift_of<MODAL>(d, t) + a.eps) * d.mass_v[v]);
+            if (MODAL && frozen) {      // keep the frozen column's norm in the sum so its total stays put
+                const double r = d.cg_r[iv];
+                acc += r * dinv * r;
+                continue;
+            }
+            a.x[iv] += alpha * a.p_new[iv];
+            const double r = d.cg_r[iv] - alpha * a.out[iv];
+            const double z = r * dinv;
             d.cg_r[iv] = r;
-            d.cg_z[iv] = z;
+            if (!a.mg) d.cg_z[iv] = z;
             acc += r * z;
         }
     }
-    emit_partial<MODAL>(d, acc, 0, s_red);
+    emit_partial<MODAL>(d, acc, d.partials + part_crit(a, a.parity ^ 1), l);
 }
 
-// One workgroup per scalar column: add the partial sums in a fixed order and update the scalars.
-//   STAGE 0: after k_cg_r0     rz, bref, beta = 0, done, iteration counter = 0
-//   STAGE 1: after k_cg_apply  pAp, alpha
-//   STAGE 2: after k_cg_update rz_new, beta, done, iteration counter += 1
-//   STAGE 3: mean of b         bmean (only when the operator is singular: eps == 0)
-template <bool MODAL, int STAGE>
-__global__ __launch_bounds__(BLOCK) void k_cg_reduce(Dev d, int nblk, double tol2, double mean_scale) {
-    __shared__ double lds[8];
-    const int nc = MODAL ? d.T + 1 : 1;
-    const int c = blockIdx.x;
-    if (STAGE == 1 || STAGE == 2) {
-        if (all_done<MODAL>(d)) return;
-    }
-    double v[2] = {0.0, 0.0};
-    for (int g = threadIdx.x; g < nblk; g += BLOCK) {
-        v[0] += d.partials[((int64_t)0 * nc + c) * nblk + g];
-        if (STAGE == 0) v[1] += d.partials[((int64_t)1 * nc + c) * nblk + g];
-    }
-    block_sum<2>(v, lds);
-    if (threadIdx.x != 0) return;
-    if (STAGE == 0) {
-        d.scal[S::RZ + c] = v[0];
-        d.scal[S::BREF + c] = v[1];
-        d.scal[S::BETA + c] = 0.0;
-        d.scal[S::ALPHA + c] = 0.0;
-        d.flags[c] = (v[0] <= tol2 * v[1]) ? 1 : 0;
-        if (c == 0) d.flags[FLAG_ITERS] = 0;
-    } else if (STAGE == 1) {
-        const bool done = d.flags[c] != 0;
-        d.scal[S::PAP + c] = v[0];
-        d.scal[S::ALPHA + c] = (done || !(v[0] > 0.0)) ? 0.0 : d.scal[S::RZ + c] / v[0];
-    } else if (STAGE == 2) {
-        if (!d.flags[c]) {
-            const double rz = d.scal[S::RZ + c];
-            d.scal[S::BETA + c] = (rz > 0.0) ? v[0] / rz : 0.0;
-            d.scal[S::RZ + c] = v[0];
-            d.flags[c] = (v[0] <= tol2 * d.scal[S::BREF + c]) ? 1 : 0;
-        }
-        if (c == 0) d.flags[FLAG_ITERS] += 1;
-    } else {
-        d.scal[S::BMEAN + c] = (c == 0) ? v[0] * mean_scale : 0.0;
-    }
+// mean of b over the null space (only when the operator is singular: eps == 0)
+__global__ __launch_bounds__(BLOCK) void k_cg_bmean(Dev d, int nblk, int nc, double mean_scale) {
+    __shared__ double lds[4];
+    double v[1] = {0.0};
+    for (int g = threadIdx.x; g < nblk; g += BLOCK) v[0] += d.partials[g];
+    block_sum<1>(v, lds);
+    if (threadIdx.x == 0) d.scal[S::BMEAN] = v[0] * mean_scale;
+    for (int c = 1 + threadIdx.x; c < nc; c += BLOCK) d.scal[S::BMEAN + c] = 0.0;
 }
 
 // Time-mode transform of node arrays: FWD  y[v][a] = sum_t Q[t][a] x[v][t]   (time -> modes)
@@ -271,36 +395,75 @@ __global__ __launch_bounds__(BLOCK) void k_time_modes(Dev d, const double *__res
 // ------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------
-template <bool MODAL>
-static int cg_iterations(Ctx *c, double *x, int n_iter, int start_parity) {
+static void cg_tiling(const Dev &d, int *ept_out, int *vt_out, int *G_out) {
+    // elements per thread: smallest power of two that keeps the number of workgroups (= partial sums
+    // every workgroup re-reduces) at or below 1024
+    int ept = 1;
+    while (ept < 8 && ((int64_t)d.V * d.TP + (int64_t)CG_NB * ept - 1) / ((int64_t)CG_NB * ept) > 1024) ept <<= 1;
+    int vt = CG_NB * ept / d.TP;
+    if (vt < 1) vt = 1;
+    *ept_out = ept;
+    *vt_out = vt;
+    *G_out = xcd_grid((d.V + vt - 1) / vt);
+}
+
+static CgArgs make_args(Ctx *c, bool modal) {
     const Dev &d = c->d;
-    const int g = xcd_grid(d.n_vtiles);
-    const int nc = MODAL ? d.T + 1 : 1;
-    const double eps = c->prm.eps, tol2 = c->prm.cg_tol * c->prm.cg_tol;
+    CgArgs a{};
+    cg_tiling(d, &a.ept, &a.vt, &a.G);
+    a.cap = a.vt * 12 + 64;          // ~7 entries per row on a triangle mesh; entries beyond cap are read from global
+    if (a.cap > 3072) a.cap = 3072;  // keep the dynamic LDS below 64 KB
+    a.nc = modal ? d.cg_ncol : 1;
+    a.pstride = modal ? a.G * d.TP : a.G;
+    a.stage = c->cg_stage_lds;
+    a.mg = (modal && c->mg.nlev > 1 && c->use_mg) ? 1 : 0;
+    a.eps = c->prm.eps;
+    a.tol2 = c->prm.cg_tol * c->prm.cg_tol;
+    return a;
+}
+
+int64_t cg_partials_needed(const Dev &d) {
+    int ept, vt, G;
+    cg_tiling(d, &ept, &vt, &G);
+    return N_PART_ARRAYS * (int64_t)d.TP * G;
+}
+
+template <bool MODAL>
+static int cg_iterations(Ctx *c, CgArgs a, double *x, int n_iter) {
+    const Dev &d = c->d;
+    const size_t lds = cg_lds_bytes(a.cap, a.vt);
     for (int it = 0; it < n_iter; ++it) {
-        const bool odd = ((start_parity + it) & 1) != 0;
-        double *p_old = odd ? d.cg_p1 : d.cg_p0;
-        double *p_new = odd ? d.cg_p0 : d.cg_p1;
-        hipLaunchKernelGGL((k_cg_apply<MODAL, true>), dim3(g), dim3(BLOCK), 0, c->stream, d, d.cg_z, p_old, p_new, d.cg_Ap, eps, 1);
-        hipLaunchKernelGGL((k_cg_reduce<MODAL, 1>), dim3(nc), dim3(BLOCK), 0, c->stream, d, g, tol2, 0.0);
-        hipLaunchKernelGGL((k_cg_update<MODAL>), dim3(g), dim3(BLOCK), 0, c->stream, d, x, p_new, eps);
-        hipLaunchKernelGGL((k_cg_reduce<MODAL, 2>), dim3(nc), dim3(BLOCK), 0, c->stream, d, g, tol2, 0.0);
+        const bool odd = (it & 1) != 0;
+        a.parity = odd ? 1 : 0;
+        a.zin = d.cg_z;
+        a.p_old = odd ? d.cg_p1 : d.cg_p0;
+        a.p_new = odd ? d.cg_p0 : d.cg_p1;
+        a.out = d.cg_Ap;
+        a.x = x;
+        hipLaunchKernelGGL((k_cg_apply<MODAL, true>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
+        hipLaunchKernelGGL((k_cg_update<MODAL>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
+        if (a.mg) {
+            int rc = mg_vcycle(c, d.cg_r, d.cg_z, d.partials + part_rz(a, a.parity ^ 1), a.ept, a.vt, a.G);
+            if (rc) return rc;
+        }
     }
     DOTS_HIP(hipGetLastError());
     return 0;
 }
 
-// Instantiate (once per eps) a hipGraph holding `unit` PCG iterations; replaying it costs one host call.
+// Instantiate (once per eps / tolerance / preconditioner) a hipGraph holding `unit` PCG iterations.
 template <bool MODAL>
-static int cg_graph_prepare(Ctx *c, double *x, int unit) {
-    if (c->cg_graph && c->cg_graph_iters == unit && c->cg_graph_eps == c->prm.eps && c->cg_graph_tol == c->prm.cg_tol) return 0;
+static int cg_graph_prepare(Ctx *c, const CgArgs &a, double *x, int unit) {
+    if (c->cg_graph && c->cg_graph_iters == unit && c->cg_graph_eps == c->prm.eps && c->cg_graph_tol == c->prm.cg_tol &&
+        c->cg_graph_mg == a.mg)
+        return 0;
     if (c->cg_graph) {
         (void)hipGraphExecDestroy(c->cg_graph);
         c->cg_graph = nullptr;
     }
     hipGraph_t graph = nullptr;
     DOTS_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    int rc = cg_iterations<MODAL>(c, x, unit, 0);
+    int rc = cg_iterations<MODAL>(c, a, x, unit);
     hipError_t e = hipStreamEndCapture(c->stream, &graph);
     if (rc != 0) return rc;
     DOTS_HIP(e);
@@ -309,41 +472,35 @@ static int cg_graph_prepare(Ctx *c, double *x, int unit) {
     c->cg_graph_iters = unit;
     c->cg_graph_eps = c->prm.eps;
     c->cg_graph_tol = c->prm.cg_tol;
+    c->cg_graph_mg = a.mg;
     return 0;
 }
 
+// PCG on the node-layout right-hand side b (already in mode space when MODAL), solution in x.
 template <bool MODAL>
-static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
+static int cg_core(Ctx *c, const double *b, double *x, dots_step_stats *stats) {
     const Dev &d = c->d;
-    const int g = xcd_grid(d.n_vtiles);
-    const int nc = MODAL ? d.T + 1 : 1;
-    const double eps = c->prm.eps, tol2 = c->prm.cg_tol * c->prm.cg_tol;
-    const bool singular = (eps == 0.0);
-    double *x = MODAL ? d.cg_x : d.phi;
-    const double *b = d.cg_b;
-
-    if (MODAL) {
-        // b^ = Q^T b (into cg_Ap as scratch), x^ = Q^T phi (warm start in mode space)
-        hipLaunchKernelGGL((k_time_modes<true>), dim3(g), dim3(BLOCK), 0, c->stream, d, d.cg_b, d.cg_p0, 1);
-        hipLaunchKernelGGL((k_time_modes<true>), dim3(g), dim3(BLOCK), 0, c->stream, d, d.phi, d.cg_x, 0);
-        b = d.cg_p0;   // consumed by k_cg_r0 before the first iteration overwrites p0 (iteration 0 writes p1)
-    }
-    // mean of b over the null space (partials were emitted by k_rhs / the forward transform)
-    const double mean_scale = !singular ? 0.0 : (MODAL ? 1.0 / d.V : 1.0 / ((double)d.V * (d.T + 1)));
-    hipLaunchKernelGGL((k_cg_reduce<MODAL, 3>), dim3(nc), dim3(BLOCK), 0, c->stream, d, g, tol2, mean_scale);
-    hipLaunchKernelGGL((k_cg_apply<MODAL, false>), dim3(g), dim3(BLOCK), 0, c->stream, d, x, nullptr, nullptr, d.cg_Ap, eps, 0);
-    hipLaunchKernelGGL((k_cg_r0<MODAL>), dim3(g), dim3(BLOCK), 0, c->stream, d, b, d.cg_Ap, eps);
-    hipLaunchKernelGGL((k_cg_reduce<MODAL, 0>), dim3(nc), dim3(BLOCK), 0, c->stream, d, g, tol2, 0.0);
+    CgArgs a = make_args(c, MODAL);
+    const size_t lds = cg_lds_bytes(a.cap, a.vt);
+    a.zin = x;
+    a.out = d.cg_Ap;
+    hipLaunchKernelGGL((k_cg_apply<MODAL, false>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
+    hipLaunchKernelGGL((k_cg_r0<MODAL>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a, b, d.cg_Ap);
+    hipLaunchKernelGGL((k_cg_begin<MODAL>), dim3(1), dim3(CG_NB), lds, c->stream, d, a);
     DOTS_HIP(hipGetLastError());
+    if (a.mg) {
+        int rc = mg_vcycle(c, d.cg_r, d.cg_z, d.partials + part_rz(a, 0), a.ept, a.vt, a.G);
+        if (rc) return rc;
+    }
 
     const int max_iter = c->prm.cg_max_iter > 0 ? c->prm.cg_max_iter : 10000;
-    const int unit = 8;   // iterations per graph replay (even, so the p ping-pong parity is preserved)
-    int rc = cg_graph_prepare<MODAL>(c, x, unit);
+    const int unit = a.mg ? 2 : 8;   // iterations per graph replay (even: the ping-pong parity is preserved)
+    int rc = cg_graph_prepare<MODAL>(c, a, x, unit);
     if (rc != 0) return rc;
     int launched = 0, iters = 0;
     bool done = false;
     // first burst sized from the previous solve (iteration counts drift slowly along the ALM)
-    int burst = c->last_cg_iters > 2 * unit ? ((c->last_cg_iters - unit) / unit) * unit : unit;
+    int burst = c->last_cg_iters > 2 * unit ? ((c->last_cg_iters - unit / 2) / unit) * unit : unit;
     while (!done && launched < max_iter) {
         for (int k = 0; k < burst / unit; ++k) DOTS_HIP(hipGraphLaunch(c->cg_graph, c->stream));
         launched += burst;
@@ -351,26 +508,47 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
         DOTS_HIP(hipMemcpyAsync(c->h_flags, d.flags, sizeof(int) * FLAG_TOTAL, hipMemcpyDeviceToHost, c->stream));
         DOTS_HIP(hipStreamSynchronize(c->stream));
         done = true;
-        for (int k = 0; k < nc; ++k) done = done && (c->h_flags[k] != 0);
+        for (int k = 0; k < a.nc; ++k) done = done && (c->h_flags[k] != 0);
         iters = c->h_flags[FLAG_ITERS];
     }
     c->last_cg_iters = iters;
-    if (MODAL) {
-        hipLaunchKernelGGL((k_time_modes<false>), dim3(g), dim3(BLOCK), 0, c->stream, d, d.cg_x, d.phi, 0);
-        DOTS_HIP(hipGetLastError());
-    }
     if (stats) {
         DOTS_HIP(hipMemcpyAsync(c->h_pinned, d.scal, sizeof(double) * S::TOTAL, hipMemcpyDeviceToHost, c->stream));
         DOTS_HIP(hipStreamSynchronize(c->stream));
         double worst = 0.0;
-        for (int k = 0; k < nc; ++k) {
-            const double br = c->h_pinned[S::BREF + k], rz = c->h_pinned[S::RZ + k];
-            if (br > 0.0 && rz / br > worst) worst = rz / br;
+        for (int k = 0; k < a.nc; ++k) {
+            const double br = c->h_pinned[S::BREF + k], cr = c->h_pinned[S::ALPHA + k];
+            if (br > 0.0 && cr / br > worst) worst = cr / br;
         }
         stats->cg_last_rel_residual = sqrt(worst);
         stats->cg_last_iterations = iters;
         stats->cg_iterations += iters;
         if (!done) stats->cg_not_converged += 1;
+    }
+    return 0;
+}
+
+template <bool MODAL>
+static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
+    const Dev &d = c->d;
+    const int gt = xcd_grid(d.n_vtiles);
+    const bool singular = (c->prm.eps == 0.0);
+    double *x = MODAL ? d.cg_x : d.phi;
+    const double *b = d.cg_b;
+    if (MODAL) {
+        // b^ = Q^T b (into p0 as scratch), x^ = Q^T phi (warm start in mode space)
+        hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_b, d.cg_p0, 1);
+        hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.phi, d.cg_x, 0);
+        b = d.cg_p0;   // consumed by k_cg_r0 before iteration 0 (which reads no p_old: beta = 0) writes p1
+    }
+    const double mean_scale = !singular ? 0.0 : (MODAL ? 1.0 / d.V : 1.0 / ((double)d.V * (d.T + 1)));
+    hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, gt, MODAL ? d.cg_ncol : 1, mean_scale);
+    DOTS_HIP(hipGetLastError());
+    int rc = cg_core<MODAL>(c, b, x, stats);
+    if (rc) return rc;
+    if (MODAL) {
+        hipLaunchKernelGGL((k_time_modes<false>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_x, d.phi, 0);
+        DOTS_HIP(hipGetLastError());
     }
     return 0;
 }
@@ -381,45 +559,82 @@ int cg_solve(Ctx *c, dots_step_stats *stats) {
 
 // y = K x on node-layout arrays with the coupled space-time operator (tests, operator parity)
 int cg_apply_operator(Ctx *c, const double *x, double *y) {
-    const int g = xcd_grid(c->d.n_vtiles);
-    hipLaunchKernelGGL((k_cg_apply<false, false>), dim3(g), dim3(BLOCK), 0, c->stream, c->d, x, nullptr, nullptr, y, c->prm.eps, 0);
+    CgArgs a = make_args(c, false);
+    a.zin = x;
+    a.out = y;
+    hipLaunchKernelGGL((k_cg_apply<false, false>), dim3(a.G), dim3(CG_NB), cg_lds_bytes(a.cap, a.vt), c->stream, c->d, a);
     DOTS_HIP(hipGetLastError());
     return 0;
 }
 
-// Time `reps` launches of the dominant kernel (fused operator application) between two hipEvents.
+// Time `reps` launches of one PCG kernel between two hipEvents.
+//   which 0: k_cg_apply (fused direction update + operator + p.Ap)     1: k_cg_update     2: one multigrid V-cycle
 int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes) {
     const Dev &d = c->d;
-    const int g = xcd_grid(d.n_vtiles);
     const bool modal = c->lap_solver == DOTS_LAP_MODAL_PCG;
-    // neutral scalars so that the kernel does its full work: beta = 0.5, no column frozen
+    CgArgs a = make_args(c, modal);
+    const size_t lds = cg_lds_bytes(a.cap, a.vt);
+    if (which == 2 && !a.mg) {
+        set_error("bench: no multigrid hierarchy on this context");
+        return DOTS_ERR_STATE;
+    }
+    // neutral scalars so that the kernels do their full work: no column frozen, beta = 1/2, alpha = 1
     DOTS_HIP(hipMemsetAsync(d.flags, 0, sizeof(int) * FLAG_TOTAL, c->stream));
-    double *hb = c->h_pinned;
-    for (int k = 0; k < S::NCMAX; ++k) hb[k] = 0.5;
-    DOTS_HIP(hipMemcpyAsync(d.scal + S::BETA, hb, sizeof(double) * S::NCMAX, hipMemcpyHostToDevice, c->stream));
     DOTS_HIP(hipMemsetAsync(d.cg_p0, 0, sizeof(double) * (size_t)d.V * d.TP, c->stream));
+    DOTS_HIP(hipMemsetAsync(d.cg_p1, 0, sizeof(double) * (size_t)d.V * d.TP, c->stream));
+    const int64_t npart = cg_partials_needed(d);
+    std::vector<double> ones((size_t)npart, 0.0);
+    for (int k = 0; k < a.nc; ++k) {   // workgroup 0 carries the totals: r.z = crit = 1 (both parities), p.Ap = 2
+        ones[(size_t)(part_rz(a, 0) + k)] = 1.0;
+        ones[(size_t)(part_rz(a, 1) + k)] = 1.0;
+        ones[(size_t)(part_crit(a, 0) + k)] = 1.0;
+        ones[(size_t)(part_crit(a, 1) + k)] = 1.0;
+        ones[(size_t)(part_pap(a) + k)] = 2.0;
+    }
+    std::vector<double> sc(S::TOTAL, 0.0);
+    for (int k = 0; k < S::NCMAX; ++k) {
+        sc[SC_RZ0 + k] = 2.0;
+        sc[SC_RZ1 + k] = 2.0;
+        sc[S::BREF + k] = 1e30;
+    }
+    DOTS_HIP(hipMemcpyAsync(d.scal, sc.data(), sizeof(double) * S::TOTAL, hipMemcpyHostToDevice, c->stream));
+    DOTS_HIP(hipMemcpyAsync(d.partials, ones.data(), sizeof(double) * (size_t)npart, hipMemcpyHostToDevice, c->stream));
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    a.tol2 = 0.0;   // nothing freezes
+    a.zin = d.cg_z;
+    a.out = d.cg_Ap;
+    a.x = d.cg_x;
+    int rc_launch = 0;
     auto launch = [&](int i) {
-        double *po = (i & 1) ? d.cg_p1 : d.cg_p0, *pn = (i & 1) ? d.cg_p0 : d.cg_p1;
-        if (which == 1) {
-            if (modal) hipLaunchKernelGGL((k_cg_update<true>), dim3(g), dim3(BLOCK), 0, c->stream, d, d.cg_x, pn, c->prm.eps);
-            else hipLaunchKernelGGL((k_cg_update<false>), dim3(g), dim3(BLOCK), 0, c->stream, d, d.cg_x, pn, c->prm.eps);
+        // the parity stays 0 so that the neutral r.z partial sums the apply kernel reads are never overwritten
+        a.parity = 0;
+        a.p_old = (i & 1) ? d.cg_p1 : d.cg_p0;
+        a.p_new = (i & 1) ? d.cg_p0 : d.cg_p1;
+        if (which == 2) {
+            rc_launch |= mg_vcycle(c, d.cg_r, d.cg_z, d.partials + part_rz(a, 1), a.ept, a.vt, a.G);
+        } else if (which == 1) {
+            if (modal) hipLaunchKernelGGL((k_cg_update<true>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
+            else hipLaunchKernelGGL((k_cg_update<false>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
         } else {
-            if (modal) hipLaunchKernelGGL((k_cg_apply<true, true>), dim3(g), dim3(BLOCK), 0, c->stream, d, d.cg_z, po, pn, d.cg_Ap, c->prm.eps, 1);
-            else hipLaunchKernelGGL((k_cg_apply<false, true>), dim3(g), dim3(BLOCK), 0, c->stream, d, d.cg_z, po, pn, d.cg_Ap, c->prm.eps, 1);
+            if (modal) hipLaunchKernelGGL((k_cg_apply<true, true>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
+            else hipLaunchKernelGGL((k_cg_apply<false, true>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
         }
     };
-    DOTS_HIP(hipMemsetAsync(d.scal + S::ALPHA, 0, sizeof(double) * S::NCMAX, c->stream));
-    for (int i = 0; i < 3; ++i) launch(i);
+    for (int i = 0; i < 2; ++i) launch(i);
+    DOTS_HIP(hipMemcpyAsync(d.partials, ones.data(), sizeof(double) * (size_t)npart, hipMemcpyHostToDevice, c->stream));
     DOTS_HIP(hipEventRecord(c->ev[6], c->stream));
     for (int i = 0; i < reps; ++i) launch(i);
     DOTS_HIP(hipEventRecord(c->ev[7], c->stream));
     DOTS_HIP(hipEventSynchronize(c->ev[7]));
+    DOTS_HIP(hipGetLastError());
+    if (rc_launch) return rc_launch;
     float t = 0.f;
     DOTS_HIP(hipEventElapsedTime(&t, c->ev[6], c->ev[7]));
     *ms = (double)t / reps;
-    const double N = (double)d.V * (d.T + 1);
-    if (which == 1) *bytes = 8.0 * N * 7.0 + 16.0 * d.V;                      // x,p,r,Ap read; x,r,z written
-    else *bytes = 12.0 * c->nnz + 4.0 * (d.V + 1) + 16.0 * d.V + 8.0 * N * 4.0;  // CSR + z,p_old read; p_new,Ap written
+    const double N = (double)d.V * (modal ? d.cg_ncol : d.T + 1);
+    if (which == 2) *bytes = 8.0 * N * 8.0;                                        // fine level: 8 vector passes
+    else if (which == 1) *bytes = 8.0 * N * (a.mg ? 6.0 : 7.0) + 16.0 * d.V;       // x,p,r,Ap read; x,r(,z) written
+    else *bytes = 12.0 * c->nnz + 4.0 * (d.V + 1) + 16.0 * d.V + 8.0 * N * 4.0;    // CSR + z,p_old read; p_new,Ap written
     return 0;
 }
 

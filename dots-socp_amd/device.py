@@ -172,6 +172,71 @@ class DeviceProblem:
         )
         return out
 
+    # ---- multigrid preconditioner of the modal PCG
+    def setup_multigrid(self, eps=0.0, omega=2.0 / 3.0, coarsest=96, mode_slice=None):
+        """Build the smoothed-aggregation hierarchy on the host and upload it (see multigrid.py).
+
+        ``mode_slice``: the time modes this context solves (default: all T+1).  Returns the
+        hierarchy summary, or None when the mesh is too small for a second level (Jacobi stays)."""
+        import scipy.sparse as sp
+
+        from . import multigrid
+
+        if self.lap_solver != "modal_pcg":
+            raise ValueError("the multigrid preconditioner needs lap_solver='modal_pcg'")
+        p = self.plan
+        K = sp.csr_matrix((p.lap_val, p.lap_col, p.lap_rowptr), shape=(p.n_vertices, p.n_vertices))
+        levels = multigrid.build_hierarchy(K, p.mass_vert, coarsest=coarsest)
+        if len(levels) < 2:
+            return None
+        sigma = p.time_eigs if mode_slice is None else p.time_eigs[mode_slice]
+        last = levels[-1]
+        Kc, Mc = last.K.toarray(), last.M.toarray()
+        inv = np.empty((last.n, last.n, sigma.size))
+        for k, s in enumerate(sigma):
+            A = Kc + (s + eps) * Mc
+            inv[:, :, k] = np.linalg.pinv(A, hermitian=True) if (s + eps) == 0.0 else np.linalg.inv(A)
+        keep = []   # host arrays must stay alive until dots_mg_setup returns
+
+        def arr(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            keep.append(a)
+            return a
+
+        lv = (_lib.MgLevel * len(levels))()
+        for l, L in enumerate(levels):
+            h = lv[l]
+            h.n = L.n
+            if l > 0:
+                h.nnz = int(L.K.nnz)
+                h.rowptr = _ptr(arr(L.K.indptr, np.int32), C.c_int32)
+                h.col = _ptr(arr(L.K.indices, np.int32), C.c_int32)
+                h.val_k = _ptr(arr(L.K.data, np.float64), C.c_double)
+                h.val_m = _ptr(arr(L.M.data, np.float64), C.c_double)
+                h.diag_k = _ptr(arr(L.dK, np.float64), C.c_double)
+                h.diag_m = _ptr(arr(L.dM, np.float64), C.c_double)
+            if L.P is not None:
+                h.n_coarse = L.P.shape[1]
+                h.p_nnz = int(L.P.nnz)
+                h.p_rowptr = _ptr(arr(L.P.indptr, np.int32), C.c_int32)
+                h.p_col = _ptr(arr(L.P.indices, np.int32), C.c_int32)
+                h.p_val = _ptr(arr(L.P.data, np.float64), C.c_double)
+                h.r_rowptr = _ptr(arr(L.R.indptr, np.int32), C.c_int32)
+                h.r_col = _ptr(arr(L.R.indices, np.int32), C.c_int32)
+                h.r_val = _ptr(arr(L.R.data, np.float64), C.c_double)
+        desc = _lib.MgDesc()
+        desc.n_levels = len(levels)
+        desc.n_cols = int(sigma.size)
+        desc.omega = float(omega)
+        desc.levels = lv
+        desc.coarse_inverse = _ptr(arr(inv, np.float64), C.c_double)
+        _lib.check(self.lib.dots_mg_setup(self._h, C.byref(desc)), "dots_mg_setup")
+        self.mg_summary = multigrid.hierarchy_summary(levels)
+        return self.mg_summary
+
+    def enable_multigrid(self, on=True):
+        _lib.check(self.lib.dots_mg_enable(self._h, 1 if on else 0), "dots_mg_enable")
+
     def bench_kernel(self, which=0, reps=50):
         ms, nbytes = C.c_double(), C.c_double()
         _lib.check(self.lib.dots_bench_kernel(self._h, int(which), int(reps), C.byref(ms), C.byref(nbytes)), "dots_bench_kernel")

@@ -189,6 +189,43 @@ enum dots_operator {
 };
 int dots_apply_operator(dots_ctx *ctx, int op, double scale, const double *in, int64_t n_in, double *out, int64_t n_out);
 
+/* ---- multigrid preconditioner of the modal PCG (optional; Jacobi is used without it) ----------
+ * Smoothed-aggregation hierarchy of the surface stiffness matrix, built on the host
+ * (dots-socp_amd/multigrid.py).  Level l holds K_l and M_l on one CSR pattern, the prolongation P_l
+ * (n_l x n_{l+1}) and its transpose; level 0 is the context's own K and vertex mass (pass NULL for
+ * its rowptr/col/val_k/val_m).  coarse_inverse is (K_L + (sigma_a + eps) M_L)^-1 for every mode a,
+ * stored [n_L][n_L][n_cols] (pseudo-inverse for a singular mode): it depends on eps, so call
+ * dots_mg_setup again when eps changes. */
+typedef struct dots_mg_level {
+    int32_t n;                 /* rows of this level */
+    int32_t nnz;               /* entries of the K/M pattern (0 for level 0) */
+    const int32_t *rowptr;     /* [n+1] */
+    const int32_t *col;        /* [nnz] */
+    const double *val_k;       /* [nnz] */
+    const double *val_m;       /* [nnz] */
+    const double *diag_k;      /* [n] (level 0: may be NULL, taken from the context) */
+    const double *diag_m;      /* [n] */
+    int32_t n_coarse;          /* rows of the next level (0 on the coarsest) */
+    int32_t p_nnz;
+    const int32_t *p_rowptr;   /* [n+1]        P: n x n_coarse */
+    const int32_t *p_col;
+    const double *p_val;
+    const int32_t *r_rowptr;   /* [n_coarse+1] R = P^T */
+    const int32_t *r_col;
+    const double *r_val;
+} dots_mg_level;
+
+typedef struct dots_mg_desc {
+    int32_t n_levels;          /* >= 2 */
+    int32_t n_cols;            /* modes the inverse is given for (= T+1 on one GPU) */
+    double omega;              /* Jacobi damping of the smoother */
+    const dots_mg_level *levels;
+    const double *coarse_inverse;
+} dots_mg_desc;
+
+int dots_mg_setup(dots_ctx *ctx, const dots_mg_desc *desc);
+int dots_mg_enable(dots_ctx *ctx, int on);   /* switch between multigrid (1) and Jacobi (0) preconditioning */
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Launch the dominant kernel (the PCG operator application) `reps` times on the context's stream
  * between two hipEvents and return the average milliseconds per launch and the algorithmic bytes
