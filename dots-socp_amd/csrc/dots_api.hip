@@ -499,16 +499,16 @@ int dots_mg_setup(dots_ctx *c, const dots_mg_desc *m) {
         if (l + 1 < m->n_levels) {
             MUP(p_rp, h.p_rowptr, h.n + 1); MUP(p_col, h.p_col, h.p_nnz); MUP(p_val, h.p_val, h.p_nnz);
             MUP(r_rp, h.r_rowptr, h.n_coarse + 1); MUP(r_col, h.r_col, h.p_nnz); MUP(r_val, h.r_val, h.p_nnz);
+            if (!h.ap_rowptr || !h.ap_col || !h.ap_val_k || !h.ap_val_m || h.ap_rowptr[h.n] != h.ap_nnz) { set_error("mg_setup: bad A*P arrays"); mg_release(c); return DOTS_ERR_ARGUMENT; }
+            for (int j = 0; j < h.ap_nnz; ++j) if (h.ap_col[j] < 0 || h.ap_col[j] >= h.n_coarse) { set_error("mg_setup: A*P index out of range"); mg_release(c); return DOTS_ERR_ARGUMENT; }
+            MUP(ap_rp, h.ap_rowptr, h.n + 1); MUP(ap_col, h.ap_col, h.ap_nnz); MUP(ap_vK, h.ap_val_k, h.ap_nnz); MUP(ap_vM, h.ap_val_m, h.ap_nnz);
         }
 #undef MUP
-        const int64_t nv = (int64_t)h.n << d.tp_shift;
-        const double *tmp = nullptr;
-        if (l == 0) {
-            L.x = d.cg_Ap;   // free between k_cg_update and the next k_cg_apply
-            if ((rc = mg_upload<double>(c, &tmp, nullptr, nv))) { mg_release(c); return rc; }
-            L.r = const_cast<double *>(tmp);
-        } else {
-            double **vecs[4] = {&L.b, &L.x, &L.x2, &L.r};
+        // level vectors; level 0 works on the PCG's own r, z and Ap buffers
+        if (l > 0) {
+            const int64_t nv = (int64_t)h.n << d.tp_shift;
+            const double *tmp = nullptr;
+            double **vecs[3] = {&L.b, &L.bt, &L.t};
             for (auto v : vecs) {
                 if ((rc = mg_upload<double>(c, &tmp, nullptr, nv))) { mg_release(c); return rc; }
                 *v = const_cast<double *>(tmp);

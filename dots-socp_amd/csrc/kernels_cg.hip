@@ -287,7 +287,7 @@ __global__ __launch_bounds__(CG_NB) void k_cg_r0(Dev d, CgArgs a, const double *
             const double dinv = 1.0 / (d.kdiag[v] + (shift_of<MODAL>(d, t) + a.eps) * d.mass_v[v]);
             const double z = dinv * r;
             d.cg_r[iv] = r;
-            if (!a.mg) d.cg_z[iv] = z;
+            d.cg_z[iv] = z;   // Jacobi z; with multigrid it is the D^-1 r the V-cycle starts from
             a0 += r * z;
             a1 += bt * dinv * bt;
         }
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(CG_NB) void k_cg_update(Dev d, CgArgs a) {
             const double r = d.cg_r[iv] - alpha * a.out[iv];
             const double z = r * dinv;
             d.cg_r[iv] = r;
-            if (!a.mg) d.cg_z[iv] = z;
+            d.cg_z[iv] = z;   // Jacobi z; with multigrid it is the D^-1 r the V-cycle starts from
             acc += r * z;
         }
     }
@@ -443,7 +443,7 @@ static int cg_iterations(Ctx *c, CgArgs a, double *x, int n_iter) {
         hipLaunchKernelGGL((k_cg_apply<MODAL, true>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
         hipLaunchKernelGGL((k_cg_update<MODAL>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
         if (a.mg) {
-            int rc = mg_vcycle(c, d.cg_r, d.cg_z, d.partials + part_rz(a, a.parity ^ 1), a.ept, a.vt, a.G);
+            int rc = mg_vcycle(c, d.cg_r, d.cg_z, d.cg_Ap, d.partials + part_rz(a, a.parity ^ 1), a.ept, a.vt, a.G);
             if (rc) return rc;
         }
     }
@@ -489,7 +489,7 @@ static int cg_core(Ctx *c, const double *b, double *x, dots_step_stats *stats) {
     hipLaunchKernelGGL((k_cg_begin<MODAL>), dim3(1), dim3(CG_NB), lds, c->stream, d, a);
     DOTS_HIP(hipGetLastError());
     if (a.mg) {
-        int rc = mg_vcycle(c, d.cg_r, d.cg_z, d.partials + part_rz(a, 0), a.ept, a.vt, a.G);
+        int rc = mg_vcycle(c, d.cg_r, d.cg_z, d.cg_Ap, d.partials + part_rz(a, 0), a.ept, a.vt, a.G);
         if (rc) return rc;
     }
 
@@ -611,7 +611,7 @@ int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes) {
         a.p_old = (i & 1) ? d.cg_p1 : d.cg_p0;
         a.p_new = (i & 1) ? d.cg_p0 : d.cg_p1;
         if (which == 2) {
-            rc_launch |= mg_vcycle(c, d.cg_r, d.cg_z, d.partials + part_rz(a, 1), a.ept, a.vt, a.G);
+            rc_launch |= mg_vcycle(c, d.cg_r, d.cg_z, d.cg_Ap, d.partials + part_rz(a, 1), a.ept, a.vt, a.G);
         } else if (which == 1) {
             if (modal) hipLaunchKernelGGL((k_cg_update<true>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
             else hipLaunchKernelGGL((k_cg_update<false>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);

@@ -6,14 +6,16 @@
 // one sparse-matrix x dense-block product with the mode index fastest in memory: a gathered
 // neighbour row is one contiguous run of doubles, exactly as in the PCG operator.
 //
-// V(1,1) cycle with damped Jacobi, written so that each level costs four kernels:
-//   down     r  = b - A (w D^-1 b)                 (pre-smoothing from a zero guess folded into the residual)
-//   restrict b' = P^T r
-//   up       x  = w D^-1 b + P x'                  (re-forms the pre-smoothed iterate, adds the correction)
-//   post     z  = x + w D^-1 (b - A x)             (on the finest level also emits the r.z partial sums
-//                                                   that the next PCG kernel re-reduces)
-// and the coarsest level is a dense per-mode inverse.  Frozen (converged) modes are skipped.
-// The cycle is symmetric (same smoother before and after, P^T restriction), as PCG requires.
+// V(1,1) cycle with damped Jacobi (weight w), symmetric as PCG requires, written so that a level
+// costs three kernels and a single neighbour gather pass.  With bt = D^-1 b (delivered by the kernel
+// that produced b) and the product A P precomputed on the host:
+//   down      t   = A bt                                           (the only SpMM on the level's own graph)
+//   restrict  b'  = P^T (b - w t),   bt' = D'^-1 b'                  (pre-smoothing x = w bt folded in: b - A x = b - w t)
+//   post      z   = w bt + P x' + w D^-1 (b - w t - (A P) x')        (x = w bt + P x';  A x = w t + (A P) x')
+// The post kernel reads only its own entries of b, bt, t plus short rows of the (much smaller) coarse
+// vector, so z may overwrite bt in place.  On the finest level post also emits the r.z partial sums
+// that the next PCG kernel re-reduces.  The coarsest level is a dense per-mode inverse.  Frozen
+// (converged) modes are skipped everywhere.
 #include "dots_dev.h"
 
 namespace dots {
@@ -27,56 +29,94 @@ struct MgArgs {
 
 __device__ __forceinline__ double mg_shift(const Dev &d, const MgArgs &a, int c) { return d.sigma[c] + a.eps; }
 
-// sum_j A[i,j] * f(j)   with A = K + s M on the level's pattern (level 0: M is the diagonal mass, no vM)
-template <typename F>
-__device__ __forceinline__ double mg_row(const MgLevelDev &L, int i, double s, F f) {
-    double sum = 0.0;
-    const int j0 = L.rp[i], j1 = L.rp[i + 1];
-    if (L.vM) {
-        for (int j = j0; j < j1; ++j) sum += (L.vK[j] + s * L.vM[j]) * f(L.col[j]);
-    } else {
-        for (int j = j0; j < j1; ++j) sum += L.vK[j] * f(L.col[j]);
-        sum += s * L.dM[i] * f(i);
-    }
-    return sum;
-}
-
 #define MG_THREAD_SETUP(nrows)                                                        \
     const int64_t e = (int64_t)blockIdx.x * MG_NB + threadIdx.x;                       \
     const int i = (int)(e >> d.tp_shift), c = (int)(e & (d.TP - 1));                   \
     if (i >= (nrows) || c >= a.ncol) return;                                           \
     if (d.flags[c]) return;
 
-__global__ __launch_bounds__(MG_NB) void k_mg_down(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, double *__restrict__ r) {
+// t = A bt with A = K + s M on the level's pattern (level 0: M is the diagonal mass, vM == nullptr)
+__global__ __launch_bounds__(MG_NB) void k_mg_down(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ bt, double *__restrict__ t) {
     MG_THREAD_SETUP(L.n)
     const double s = mg_shift(d, a, c);
-    const double Ax = mg_row(L, i, s, [&](int u) { return a.omega * b[(u << d.tp_shift) + c] / (L.dK[u] + s * L.dM[u]); });
-    r[(i << d.tp_shift) + c] = b[(i << d.tp_shift) + c] - Ax;
-}
-
-__global__ __launch_bounds__(MG_NB) void k_mg_restrict(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ r, double *__restrict__ bc) {
-    MG_THREAD_SETUP(L.nc)
+    const int sh = d.tp_shift;
     double sum = 0.0;
-    for (int j = L.r_rp[i]; j < L.r_rp[i + 1]; ++j) sum += L.r_val[j] * r[(L.r_col[j] << d.tp_shift) + c];
-    bc[(i << d.tp_shift) + c] = sum;
+    int j = L.rp[i];
+    const int j1 = L.rp[i + 1];
+    if (L.vM) {
+        for (; j + 4 <= j1; j += 4) {
+            const double x0 = bt[(L.col[j] << sh) + c], x1 = bt[(L.col[j + 1] << sh) + c], x2 = bt[(L.col[j + 2] << sh) + c],
+                         x3 = bt[(L.col[j + 3] << sh) + c];
+            sum += ((L.vK[j] + s * L.vM[j]) * x0 + (L.vK[j + 1] + s * L.vM[j + 1]) * x1) +
+                   ((L.vK[j + 2] + s * L.vM[j + 2]) * x2 + (L.vK[j + 3] + s * L.vM[j + 3]) * x3);
+        }
+        for (; j < j1; ++j) sum += (L.vK[j] + s * L.vM[j]) * bt[(L.col[j] << sh) + c];
+    } else {
+        for (; j + 4 <= j1; j += 4) {
+            const double x0 = bt[(L.col[j] << sh) + c], x1 = bt[(L.col[j + 1] << sh) + c], x2 = bt[(L.col[j + 2] << sh) + c],
+                         x3 = bt[(L.col[j + 3] << sh) + c];
+            sum += (L.vK[j] * x0 + L.vK[j + 1] * x1) + (L.vK[j + 2] * x2 + L.vK[j + 3] * x3);
+        }
+        for (; j < j1; ++j) sum += L.vK[j] * bt[(L.col[j] << sh) + c];
+        sum += s * L.dM[i] * bt[(i << sh) + c];
+    }
+    t[(i << sh) + c] = sum;
 }
 
-__global__ __launch_bounds__(MG_NB) void k_mg_up(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *__restrict__ xc,
-                                               double *__restrict__ x) {
-    MG_THREAD_SETUP(L.n)
-    const double s = mg_shift(d, a, c);
-    double sum = a.omega * b[(i << d.tp_shift) + c] / (L.dK[i] + s * L.dM[i]);
-    for (int j = L.p_rp[i]; j < L.p_rp[i + 1]; ++j) sum += L.p_val[j] * xc[(L.p_col[j] << d.tp_shift) + c];
-    x[(i << d.tp_shift) + c] = sum;
+// b' = R (b - w t),  bt' = b' / diag(A')   for the next coarser level (dKc, dMc: its diagonals)
+__global__ __launch_bounds__(MG_NB) void k_mg_restrict(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *__restrict__ t,
+                                                     const double *__restrict__ dKc, const double *__restrict__ dMc, double *__restrict__ bc,
+                                                     double *__restrict__ btc) {
+    MG_THREAD_SETUP(L.nc)
+    const int sh = d.tp_shift;
+    const double w = a.omega;
+    double sum = 0.0;
+    int j = L.r_rp[i];
+    const int j1 = L.r_rp[i + 1];
+    for (; j + 4 <= j1; j += 4) {
+        const int u0 = (L.r_col[j] << sh) + c, u1 = (L.r_col[j + 1] << sh) + c, u2 = (L.r_col[j + 2] << sh) + c,
+                  u3 = (L.r_col[j + 3] << sh) + c;
+        const double b0 = b[u0], b1 = b[u1], b2 = b[u2], b3 = b[u3];
+        const double t0 = t[u0], t1 = t[u1], t2 = t[u2], t3 = t[u3];
+        sum += (L.r_val[j] * (b0 - w * t0) + L.r_val[j + 1] * (b1 - w * t1)) +
+               (L.r_val[j + 2] * (b2 - w * t2) + L.r_val[j + 3] * (b3 - w * t3));
+    }
+    for (; j < j1; ++j) {
+        const int u = (L.r_col[j] << sh) + c;
+        sum += L.r_val[j] * (b[u] - w * t[u]);
+    }
+    const int ic = (i << sh) + c;
+    bc[ic] = sum;
+    btc[ic] = sum / (dKc[i] + mg_shift(d, a, c) * dMc[i]);
 }
 
-__global__ __launch_bounds__(MG_NB) void k_mg_post(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *__restrict__ x,
-                                                 double *__restrict__ z) {
+// P x' and (A P) x' for row i, column c
+__device__ __forceinline__ void mg_coarse_terms(const Dev &d, const MgLevelDev &L, int i, int c, double s, const double *xc, double *corr,
+                                                double *apx) {
+    const int sh = d.tp_shift;
+    double p = 0.0, q = 0.0;
+    for (int j = L.p_rp[i]; j < L.p_rp[i + 1]; ++j) p += L.p_val[j] * xc[(L.p_col[j] << sh) + c];
+    int j = L.ap_rp[i];
+    const int j1 = L.ap_rp[i + 1];
+    for (; j + 4 <= j1; j += 4) {
+        const double x0 = xc[(L.ap_col[j] << sh) + c], x1 = xc[(L.ap_col[j + 1] << sh) + c], x2 = xc[(L.ap_col[j + 2] << sh) + c],
+                     x3 = xc[(L.ap_col[j + 3] << sh) + c];
+        q += ((L.ap_vK[j] + s * L.ap_vM[j]) * x0 + (L.ap_vK[j + 1] + s * L.ap_vM[j + 1]) * x1) +
+             ((L.ap_vK[j + 2] + s * L.ap_vM[j + 2]) * x2 + (L.ap_vK[j + 3] + s * L.ap_vM[j + 3]) * x3);
+    }
+    for (; j < j1; ++j) q += (L.ap_vK[j] + s * L.ap_vM[j]) * xc[(L.ap_col[j] << sh) + c];
+    *corr = p;
+    *apx = q;
+}
+
+__global__ __launch_bounds__(MG_NB) void k_mg_post(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *bt,
+                                                 const double *__restrict__ t, const double *__restrict__ xc, double *z) {
     MG_THREAD_SETUP(L.n)
-    const double s = mg_shift(d, a, c);
-    const double Ax = mg_row(L, i, s, [&](int u) { return x[(u << d.tp_shift) + c]; });
+    const double s = mg_shift(d, a, c), w = a.omega;
+    double corr, apx;
+    mg_coarse_terms(d, L, i, c, s, xc, &corr, &apx);
     const int iv = (i << d.tp_shift) + c;
-    z[iv] = x[iv] + a.omega * (b[iv] - Ax) / (L.dK[i] + s * L.dM[i]);
+    z[iv] = w * bt[iv] + corr + w * (b[iv] - w * t[iv] - apx) / (L.dK[i] + s * L.dM[i]);
 }
 
 // dense per-mode solve on the coarsest level: x[i][c] = sum_j inv[i][j][c] b[j][c]
@@ -89,9 +129,10 @@ __global__ __launch_bounds__(MG_NB) void k_mg_coarse(Dev d, MgArgs a, int n, con
 }
 
 // Finest-level post-smoothing on the PCG's own tiling (so that the r.z partial sums land where the
-// next k_cg_apply expects them): z = x + w D^-1 (r - A x), partial sums of r.z per workgroup and column.
-__global__ __launch_bounds__(1024) void k_mg_post_fine(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *__restrict__ x,
-                                                       double *__restrict__ z, double *__restrict__ part, int ept, int vt) {
+// next k_cg_apply expects them).  z overwrites bt in place.
+__global__ __launch_bounds__(1024) void k_mg_post_fine(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *bt,
+                                                       const double *__restrict__ t, const double *__restrict__ xc, double *z,
+                                                       double *__restrict__ part, int ept, int vt) {
     __shared__ double red[1024];
     const int tid = threadIdx.x;
     const int c = tid & (d.TP - 1);
@@ -99,60 +140,63 @@ __global__ __launch_bounds__(1024) void k_mg_post_fine(Dev d, MgLevelDev L, MgAr
     double acc = 0.0;
     const bool live = c < a.ncol && !d.flags[c];
     if (live) {
-        const double s = mg_shift(d, a, c);
+        const double s = mg_shift(d, a, c), w = a.omega;
         for (int q = 0; q < ept; ++q) {
             const int el = tid + q * 1024;
             const int vl = el >> d.tp_shift;
             const int i = tile * vt + vl;
             if (vl >= vt || i >= L.n) continue;
-            const double Ax = mg_row(L, i, s, [&](int u) { return x[(u << d.tp_shift) + c]; });
+            double corr, apx;
+            mg_coarse_terms(d, L, i, c, s, xc, &corr, &apx);
             const int iv = (i << d.tp_shift) + c;
-            const double zi = x[iv] + a.omega * (b[iv] - Ax) / (L.dK[i] + s * L.dM[i]);
+            const double bi = b[iv];
+            const double zi = w * bt[iv] + corr + w * (bi - w * t[iv] - apx) / (L.dK[i] + s * L.dM[i]);
             z[iv] = zi;
-            acc += b[iv] * zi;
+            acc += bi * zi;
         }
     }
     red[tid] = acc;
     __syncthreads();
     const int j = tid >> d.tp_shift, J = 1024 >> d.tp_shift;
     if (j == 0 && c < a.ncol) {
-        double t = 0.0;
-        for (int k = 0; k < J; ++k) t += red[c + (k << d.tp_shift)];
-        part[((int64_t)blockIdx.x << d.tp_shift) + c] = t;
+        double tsum = 0.0;
+        for (int k = 0; k < J; ++k) tsum += red[c + (k << d.tp_shift)];
+        part[((int64_t)blockIdx.x << d.tp_shift) + c] = tsum;
     }
 }
 
 static inline int mg_grid(const Dev &d, int rows) { return (int)((((int64_t)rows << d.tp_shift) + MG_NB - 1) / MG_NB); }
 
-// Enqueue one V-cycle: z = MG(r) for every live column; r.z partial sums go to `rz_part`.
-int mg_vcycle(Ctx *c, const double *r, double *z, double *rz_part, int ept, int vt, int G) {
+// Enqueue one V-cycle.  r: residual; z: holds D^-1 r on entry (written by the PCG update kernel) and the
+// preconditioned residual on exit; r.z partial sums go to `rz_part`.  Level 0 uses `t0` as scratch.
+int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int ept, int vt, int G) {
     const Dev &d = c->d;
     const MgDev &m = c->mg;
     MgArgs a{c->prm.eps, m.omega, d.cg_ncol};
     const int nl = m.nlev;
-    const double *b = r;
     // down sweep
     for (int l = 0; l + 1 < nl; ++l) {
         const MgLevelDev &L = m.lv[l];
-        hipLaunchKernelGGL(k_mg_down, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, b, L.r);
-        hipLaunchKernelGGL(k_mg_restrict, dim3(mg_grid(d, L.nc)), dim3(MG_NB), 0, c->stream, d, L, a, L.r, m.lv[l + 1].b);
-        b = m.lv[l + 1].b;
+        const MgLevelDev &C = m.lv[l + 1];
+        const double *b = (l == 0) ? r : L.b;
+        const double *bt = (l == 0) ? z : L.bt;
+        double *t = (l == 0) ? t0 : L.t;
+        hipLaunchKernelGGL(k_mg_down, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, bt, t);
+        hipLaunchKernelGGL(k_mg_restrict, dim3(mg_grid(d, L.nc)), dim3(MG_NB), 0, c->stream, d, L, a, b, t, C.dK, C.dM, C.b, C.bt);
     }
-    // coarsest
+    // coarsest: the solution lands in its bt slot, which plays the role of z for that level
     {
         const MgLevelDev &L = m.lv[nl - 1];
-        hipLaunchKernelGGL(k_mg_coarse, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, a, L.n, m.coarse_inv, L.b, L.x);
+        hipLaunchKernelGGL(k_mg_coarse, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, a, L.n, m.coarse_inv, L.b, L.bt);
     }
-    // up sweep
+    // up sweep: level l's result is written over its bt
     for (int l = nl - 2; l >= 0; --l) {
         const MgLevelDev &L = m.lv[l];
-        const double *bl = (l == 0) ? r : L.b;
-        const double *xc = (l + 1 == nl - 1) ? m.lv[l + 1].x : m.lv[l + 1].x2;
-        hipLaunchKernelGGL(k_mg_up, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, bl, xc, L.x);
+        const double *xc = m.lv[l + 1].bt;
         if (l == 0)
-            hipLaunchKernelGGL(k_mg_post_fine, dim3(G), dim3(1024), 0, c->stream, d, L, a, bl, L.x, z, rz_part, ept, vt);
+            hipLaunchKernelGGL(k_mg_post_fine, dim3(G), dim3(1024), 0, c->stream, d, L, a, r, z, t0, xc, z, rz_part, ept, vt);
         else
-            hipLaunchKernelGGL(k_mg_post, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, bl, L.x, L.x2);
+            hipLaunchKernelGGL(k_mg_post, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, L.b, L.bt, L.t, xc, L.bt);
     }
     DOTS_HIP(hipGetLastError());
     return 0;

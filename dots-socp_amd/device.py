@@ -191,11 +191,9 @@ class DeviceProblem:
             return None
         sigma = p.time_eigs if mode_slice is None else p.time_eigs[mode_slice]
         last = levels[-1]
-        Kc, Mc = last.K.toarray(), last.M.toarray()
         inv = np.empty((last.n, last.n, sigma.size))
         for k, s in enumerate(sigma):
-            A = Kc + (s + eps) * Mc
-            inv[:, :, k] = np.linalg.pinv(A, hermitian=True) if (s + eps) == 0.0 else np.linalg.inv(A)
+            inv[:, :, k] = multigrid.coarse_inverse(last, float(s + eps))
         keep = []   # host arrays must stay alive until dots_mg_setup returns
 
         def arr(a, dtype):
@@ -224,6 +222,11 @@ class DeviceProblem:
                 h.r_rowptr = _ptr(arr(L.R.indptr, np.int32), C.c_int32)
                 h.r_col = _ptr(arr(L.R.indices, np.int32), C.c_int32)
                 h.r_val = _ptr(arr(L.R.data, np.float64), C.c_double)
+                h.ap_nnz = int(L.KP.nnz)
+                h.ap_rowptr = _ptr(arr(L.KP.indptr, np.int32), C.c_int32)
+                h.ap_col = _ptr(arr(L.KP.indices, np.int32), C.c_int32)
+                h.ap_val_k = _ptr(arr(L.KP.data, np.float64), C.c_double)
+                h.ap_val_m = _ptr(arr(L.MP.data, np.float64), C.c_double)
         desc = _lib.MgDesc()
         desc.n_levels = len(levels)
         desc.n_cols = int(sigma.size)

@@ -25,25 +25,41 @@ class MgLevel:
     M: sp.csr_matrix            # mass on this level, same pattern as K (explicit zeros kept)
     P: sp.csr_matrix | None     # prolongation to this level from the next coarser one (n x n_coarse)
     R: sp.csr_matrix | None     # restriction = P^T (n_coarse x n)
+    KP: sp.csr_matrix | None = None   # K @ P  (n x n_coarse), used by the fused post-smoothing kernel
+    MP: sp.csr_matrix | None = None   # M @ P on the pattern of KP
     dK: np.ndarray = field(default=None)   # diag(K)
     dM: np.ndarray = field(default=None)   # diag(M)
+    cand: np.ndarray = field(default=None)  # near-null-space candidate of K on this level (K @ cand = 0)
 
 
 def _align_to_pattern(K: sp.csr_matrix, M: sp.csr_matrix) -> sp.csr_matrix:
     """M re-stored on the sparsity pattern of K (pattern(M) must be a subset; missing entries are 0.0)."""
-    n = K.shape[0]
+    n, ncol = K.shape
     M = M.tocsr()
     M.sort_indices()
     rows_k = np.repeat(np.arange(n, dtype=np.int64), np.diff(K.indptr))
     rows_m = np.repeat(np.arange(n, dtype=np.int64), np.diff(M.indptr))
-    key_k = rows_k * n + K.indices
-    key_m = rows_m * n + M.indices
+    key_k = rows_k * ncol + K.indices
+    key_m = rows_m * ncol + M.indices
     pos = np.searchsorted(key_k, key_m)
     if pos.size and (pos.max() >= key_k.size or not np.array_equal(key_k[pos], key_m)):
         raise ValueError("mass pattern is not contained in the stiffness pattern")
     data = np.zeros(K.nnz)
     data[pos] = M.data
     return sp.csr_matrix((data, K.indices.copy(), K.indptr.copy()), shape=K.shape)
+
+
+def _pattern_union(*mats) -> sp.csr_matrix:
+    """CSR matrix of ones on the union of the (non-negative) arguments' patterns, sorted indices."""
+    acc = None
+    for m in mats:
+        m = sp.csr_matrix(m)
+        m = sp.csr_matrix((np.ones(m.nnz), m.indices, m.indptr), shape=m.shape)
+        acc = m if acc is None else acc + m
+    acc = acc.tocsr()
+    acc.sort_indices()
+    acc.data[:] = 1.0
+    return acc
 
 
 def _strength_graph(K: sp.csr_matrix, theta: float) -> sp.csr_matrix:
@@ -96,12 +112,16 @@ def build_hierarchy(K: sp.csr_matrix, mass: np.ndarray, max_levels: int = 8, coa
     K = sp.csr_matrix(K, dtype=np.float64)
     K.sort_indices()
     M = sp.diags(np.asarray(mass, dtype=np.float64)).tocsr()
+    cand = np.ones(K.shape[0])
     levels: List[MgLevel] = []
     for lvl in range(max_levels):
         n = K.shape[0]
-        # give M the pattern of K (explicit zeros) so the device stores one index array per level
-        Mp = _align_to_pattern(K, M)
-        level = MgLevel(n=n, K=K, M=Mp, P=None, R=None, dK=K.diagonal().copy(), dM=Mp.diagonal().copy())
+        # K and M on one pattern (explicit zeros where needed) so the device stores one index array per
+        # level.  scipy prunes numerically-zero results of sparse products (a flat mesh has cot 90 = 0
+        # entries), so the union pattern is formed from absolute values, which cannot cancel.
+        pat = _pattern_union(abs(K), abs(M))
+        K, Mp = _align_to_pattern(pat, K), _align_to_pattern(pat, M)
+        level = MgLevel(n=n, K=K, M=Mp, P=None, R=None, dK=K.diagonal().copy(), dM=Mp.diagonal().copy(), cand=cand.copy())
         levels.append(level)
         if n <= coarsest or lvl == max_levels - 1:
             break
@@ -110,8 +130,11 @@ def build_hierarchy(K: sp.csr_matrix, mass: np.ndarray, max_levels: int = 8, coa
         n_c = int(agg.max()) + 1
         if n_c >= n * 0.9 or n_c < 2:
             break
-        counts = np.bincount(agg, minlength=n_c).astype(np.float64)
-        Pt = sp.csr_matrix((1.0 / np.sqrt(counts[agg]), (np.arange(n), agg)), shape=(n, n_c))
+        # tentative prolongator from the near-null-space candidate B (B = 1 on the finest level; on
+        # coarser levels its coarse representation, so that P_l B_{l+1} = B_l exactly)
+        norms = np.sqrt(np.bincount(agg, weights=cand * cand, minlength=n_c))
+        Pt = sp.csr_matrix((cand / norms[agg], (np.arange(n), agg)), shape=(n, n_c))
+        cand = norms
         d = K.diagonal()
         rho = float(np.max(np.asarray(abs(K).sum(axis=1)).ravel() / d))        # Gershgorin bound of rho(D^-1 K)
         P = (Pt - sp.diags(omega_p / rho / d) @ (K @ Pt)).tocsr()
@@ -119,8 +142,11 @@ def build_hierarchy(K: sp.csr_matrix, mass: np.ndarray, max_levels: int = 8, coa
         level.P = P
         level.R = P.T.tocsr()
         level.R.sort_indices()
+        pat_ap = _pattern_union(abs(K) @ abs(P), abs(Mp) @ abs(P))
+        level.KP = _align_to_pattern(pat_ap, (K @ P).tocsr())
+        level.MP = _align_to_pattern(pat_ap, (Mp @ P).tocsr())
         K = (level.R @ K @ P).tocsr()
-        M = (level.R @ M @ P).tocsr()
+        M = (level.R @ Mp @ P).tocsr()
         K.sort_indices()
         M.sort_indices()
     return levels
@@ -137,6 +163,17 @@ def hierarchy_summary(levels: List[MgLevel]) -> dict:
     }
 
 
+def coarse_inverse(level: MgLevel, shift: float) -> np.ndarray:
+    """Dense (pseudo-)inverse of K_L + shift M_L on the coarsest level.  With shift == 0 the matrix is
+    singular (one null vector); the cutoff is explicit because the null eigenvalue (~1e-17 relative)
+    sits right at numpy's default rank threshold."""
+    A = level.K.toarray() + shift * level.M.toarray()
+    A = 0.5 * (A + A.T)
+    if shift == 0.0:
+        return np.linalg.pinv(A, rcond=1e-10, hermitian=True)
+    return np.linalg.inv(A)
+
+
 class CpuVcycle:
     """Reference V(nu,nu)-cycle with damped Jacobi (CPU, one shifted system).  Mirrors what the device
     kernels do for every mode; used by tests and for tuning, not by the product path."""
@@ -145,8 +182,7 @@ class CpuVcycle:
         self.levels, self.shift, self.omega, self.nu = levels, shift, omega, nu
         self.A = [(lv.K + shift * lv.M).tocsr() for lv in levels]
         self.dinv = [1.0 / (lv.dK + shift * lv.dM) for lv in levels]
-        Ac = self.A[-1].toarray()
-        self.coarse_inv = np.linalg.pinv(Ac, hermitian=True) if shift == 0.0 else np.linalg.inv(Ac)
+        self.coarse_inv = coarse_inverse(levels[-1], shift)
 
     def cycle(self, b, l=0):
         if l == len(self.levels) - 1:
@@ -160,6 +196,17 @@ class CpuVcycle:
         for _ in range(self.nu):
             x = x + self.omega * dinv * (b - A @ x)
         return x
+
+    def cycle_fused(self, b, l=0):
+        """The same V(1,1) cycle in the three-kernel form the device uses (t = A D^-1 b kept, A P precomputed)."""
+        if l == len(self.levels) - 1:
+            return self.coarse_inv @ b
+        A, dinv, lv, w = self.A[l], self.dinv[l], self.levels[l], self.omega
+        bt = dinv * b
+        t = A @ bt                                            # k_mg_down
+        xc = self.cycle_fused(lv.R @ (b - w * t), l + 1)      # k_mg_restrict, recursion
+        AP = lv.KP + self.shift * lv.MP
+        return w * bt + lv.P @ xc + w * dinv * (b - w * t - AP @ xc)   # k_mg_post
 
     def __call__(self, b):
         return self.cycle(b)

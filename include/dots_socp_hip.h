@@ -213,6 +213,12 @@ typedef struct dots_mg_level {
     const int32_t *r_rowptr;   /* [n_coarse+1] R = P^T */
     const int32_t *r_col;
     const double *r_val;
+    int32_t ap_nnz;            /* K P and M P (n x n_coarse) on one pattern: the post-smoothing kernel applies A P */
+    int32_t reserved;
+    const int32_t *ap_rowptr;  /* [n+1] */
+    const int32_t *ap_col;
+    const double *ap_val_k;
+    const double *ap_val_m;
 } dots_mg_level;
 
 typedef struct dots_mg_desc {
