@@ -1,0 +1,229 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol the header declares, the
+host control logic takes the same decisions as the oracle's restatement of the reference, and the
+host-side operator assembly matches the oracle's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import ROOT, has_gpu, load_oracle
+
+O = load_oracle()
+
+
+# ---------------------------------------------------------------------------- C ABI
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "dots_socp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dots_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dots_socp_amd import _lib
+
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert set(_lib.EXPORTS) == set(names)
+    assert lib.dots_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """Compile a probe with gcc against the header and compare sizes/offsets with the ctypes mirror."""
+    from dots_socp_amd import _lib
+
+    src = tmp_path / "probe.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "dots_socp_hip.h"\n'
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(dots_problem_desc), sizeof(dots_params),"
+        " sizeof(dots_step_stats), sizeof(dots_mg_level), sizeof(dots_mg_desc), offsetof(dots_params, cg_tol),"
+        " offsetof(dots_mg_level, ap_rowptr)); return 0;}\n"
+    )
+    exe = tmp_path / "probe"
+    assert os.system(f"gcc -I{ROOT}/include {src} -o {exe}") == 0
+    out = os.popen(str(exe)).read().split()
+    want = [ctypes.sizeof(_lib.ProblemDesc), ctypes.sizeof(_lib.Params), ctypes.sizeof(_lib.StepStats),
+            ctypes.sizeof(_lib.MgLevel), ctypes.sizeof(_lib.MgDesc), _lib.Params.cg_tol.offset, _lib.MgLevel.ap_rowptr.offset]
+    assert [int(x) for x in out] == want
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the failure mode on a machine without a GPU")
+def test_no_silent_cpu_fallback():
+    from dots_socp_amd import _lib, meshes
+    from dots_socp_amd.socp import solver_socp
+
+    geom, _ = meshes.example("sphere", level=1)
+    with pytest.raises(_lib.HipLibraryError):
+        solver_socp(4, geom, nit=1)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "dots-socp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "dots_oracle" not in text and "oracle/" not in text.replace("the oracle", ""), f
+
+
+# ---------------------------------------------------------------------------- control logic
+def test_penalty_policy_matches_oracle():
+    from dots_socp_amd.control import AdjustAdmmParam
+
+    a, b = AdjustAdmmParam(), O.PenaltyPolicy()
+    hits = []
+    for it in range(1200):
+        x, y = a.is_to_adjust(it), b.is_to_adjust(it)
+        assert x == y
+        if x:
+            hits.append(it)
+    assert hits[:8] == [2, 5, 8, 11, 14, 17, 24, 31]        # schedule of admm_tools.py:43-48
+    for gap in np.concatenate([np.logspace(-3, 3, 200), [1.0, 1.2, 1.5, 2, 2.5, 3, 5, 10, 20, 35, 50]]):
+        assert AdjustAdmmParam.adjust_factor(gap) == O.PenaltyPolicy.factor(gap)
+        assert a.get_updated_value(0.7, gap) == b.updated(0.7, gap)
+    assert a.get_updated_value(900.0, 100.0) == 1000.0 and a.get_updated_value(1.5e-3, 1e-3) == 1e-3
+    nan = float("nan")
+    for row in ([1e-3, 2e-3, 1e-4], [nan, 1e-3, 1e-3], [1e-3, nan, 1e-3], [6e-3, 1e-3, 1e-3]):
+        p, q = AdjustAdmmParam(), O.PenaltyPolicy()
+        assert p.is_to_scale_matrix(150, row) == q.is_to_rescale_z(150, row)
+        assert p.is_to_scale_matrix(50, row) is False
+    assert [it for it in range(400) if AdjustAdmmParam.is_to_scale(it)] == [10, 50, 150, 250, 350]
+
+
+def _drive_validators(seed, n_iter=400, tol=1e-3):
+    """Feed the same synthetic error streams to both implementations and compare every decision."""
+    from dots_socp_amd.control import AdaptiveValidator, AdjustAdmmParam, ConditionValidator, ErrorCondition, max_of_list_with_none
+
+    rng = np.random.default_rng(seed)
+    base = 10.0 ** rng.uniform(-1.0, 0.5, size=7)
+    decay = rng.uniform(0.97, 0.995, size=7)
+    state = {"it": 0}
+
+    def err(i):
+        e = base[i] * decay[i] ** state["it"] * (1.0 + 0.3 * np.sin(0.37 * state["it"] + i))
+        return [float(e), float(e) if i < 4 else None]
+
+    mine = AdaptiveValidator(ConditionValidator([ErrorCondition((lambda i=i: err(i)), tol, str(i)) for i in range(7)],
+                                                [6, 2, 0, 3, 1, 4, 5]))
+    theirs = O.LazyKKT([(lambda i=i: err(i)) for i in range(7)], tol, order=[6, 2, 0, 3, 1, 4, 5])
+    pa, pb = AdjustAdmmParam(), O.PenaltyPolicy()
+    log = []
+    for it in range(n_iter):
+        state["it"] = it
+        adjust = pa.is_to_adjust(it)
+        assert adjust == pb.is_to_adjust(it)
+        req = [0, 1, 2, 3] if adjust else None
+        if adjust:
+            mine.reset_counter()
+            theirs.reset_counter()
+        p1, _ = mine.validate(req)
+        p2, _ = theirs.validate(req)
+        o1, s1 = mine.collect()
+        o2, s2 = theirs.collect()
+        if adjust:
+            mine.reset_counter()
+            theirs.reset_counter()
+        assert p1 == p2 and o1 == o2 and s1 == s2, it
+        e = max_of_list_with_none([o1[i] for i in (0, 2, 4, 5)])
+        if e is not None:
+            mine.set_error_and_tolerance(e, tol)
+            theirs.set_error(e, tol)
+        log.append([i for i, v in enumerate(o1) if v is not None])
+        if p1:
+            break
+    return log
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_lazy_validator_matches_oracle(seed):
+    log = _drive_validators(seed)
+    assert any(len(x) == 0 for x in log) and any(len(x) >= 4 for x in log)   # both skipped and required rounds occur
+
+
+def test_running_history_record_semantics():
+    from dots_socp_amd.control import RunningHistory
+
+    h = RunningHistory(5)
+    h.start()
+    assert np.all(np.isinf(h.get_current_kkt_errors()))
+    h.record(0, [1, None, 2, None, None, None, None])
+    h.record(1, [None] * 7)
+    h.record(1, [3, 3, 3, 3, 3, 3, 3], history={"Transportation cost": 0.5})     # same iteration: overwrite
+    h.end()
+    assert h.kkt_errors.shape == (2, 7) and np.isnan(h.kkt_errors[0, 1]) and h.kkt_errors[1, 0] == 3
+    assert h.kkt_iteration.tolist() == [0, 1] and h.history["Transportation cost"].tolist() == [np.inf, 0.5]
+    with pytest.raises(ValueError):
+        h.record(0, [0] * 7)
+
+
+# ---------------------------------------------------------------------------- assembly
+@pytest.mark.parametrize("reorder", [False, True])
+@pytest.mark.parametrize("mesh", ["sphere", "torus", "plane", "knot"])
+def test_plan_matches_oracle_assembly(mesh, reorder):
+    from dots_socp_amd import geometry, meshes
+
+    kw = dict(sphere=dict(level=2), torus=dict(nu=14, nv=9), plane=dict(n=7), knot=dict(nu=40, nv=6))[mesh]
+    geom, _ = meshes.example(mesh, **kw)
+    T = 5
+    plan = geometry.build_plan(T, geom, reorder=reorder)
+    s = O.OracleSolver(T, geom)
+    pv = plan.perm_vert if reorder else np.arange(s.V)
+    pf = plan.perm_tri if reorder else np.arange(s.F)
+    assert sorted(pv.tolist()) == list(range(s.V)) and sorted(pf.tolist()) == list(range(s.F))
+    assert np.array_equal(pv[plan.triangles], np.asarray(geom["triangles"])[pf])
+    K = sp.csr_matrix((plan.lap_val, plan.lap_col, plan.lap_rowptr), shape=(s.V, s.V))
+    want = (-s.L)[pv][:, pv]
+    assert abs(K - want).max() < 1e-12 * abs(want).max()          # K = G^T diag(area) G = -cot Laplacian
+    assert np.allclose(plan.mass_vert, s.mass_v[pv], rtol=1e-14)
+    assert np.allclose(plan.area_tri, s.area_f[pf], rtol=1e-14)
+    assert np.allclose(plan.hat_grad, s.hat[pf], rtol=1e-12, atol=1e-12)
+    assert np.allclose(plan.mu0, np.asarray(geom["mu0"])[pv]) and np.allclose(plan.mu1, np.asarray(geom["mu1"])[pv])
+    # corner lists: every corner exactly once, under the vertex it belongs to
+    assert plan.corner_ptr[0] == 0 and plan.corner_ptr[-1] == 3 * s.F
+    owner = np.repeat(np.arange(s.V), np.diff(plan.corner_ptr))
+    assert np.array_equal(plan.triangles.reshape(-1)[plan.corner_idx], owner)
+    assert sorted(plan.corner_idx.tolist()) == list(range(3 * s.F))
+    # time modes diagonalise the reference's Neumann matrix
+    Q, sig = plan.time_modes, plan.time_eigs
+    Lt = O.time_neumann_laplacian(T, 1.0 / T)
+    assert np.max(np.abs(Q.T @ (-Lt) @ Q - np.diag(sig))) < 1e-10 and np.max(np.abs(Q.T @ Q - np.eye(T + 1))) < 1e-13
+    assert np.allclose(np.sort(sig), np.sort(-s.lap_inv.eigval))
+
+
+def test_plan_rejects_bad_input():
+    from dots_socp_amd import geometry, meshes
+
+    geom, _ = meshes.example("sphere", level=1)
+    bad = dict(geom)
+    bad["triangles"] = np.asarray(geom["triangles"]).copy()
+    bad["triangles"][0, 0] = 10 ** 6
+    with pytest.raises(ValueError):
+        geometry.build_plan(4, bad)
+    bad = dict(geom)
+    bad["mu0"] = np.ones(3)
+    with pytest.raises(ValueError):
+        geometry.build_plan(4, bad)
+    bad = dict(geom)
+    bad["triangles"] = np.asarray(geom["triangles"]).copy()
+    bad["triangles"][0] = [0, 0, 1]          # degenerate triangle
+    with pytest.raises(ValueError):
+        geometry.build_plan(4, bad, reorder=False)
+
+
+def test_mesh_generators():
+    from dots_socp_amd import meshes
+
+    for (v, t), chi in ((meshes.icosphere(3), 2), (meshes.torus(20, 12), 0), (meshes.torus_knot_tube(2, 5, 48, 8), 0),
+                        (meshes.plane(9), 1)):
+        e = meshes._unique_edges(t)
+        assert v.shape[0] - e.shape[0] + t.shape[0] == chi
+        assert np.all(meshes.triangle_areas(v, t) > 0) and np.unique(t).size == v.shape[0]
+    g, scale = meshes.example("sphere", level=2)
+    assert abs(g["mu0"].sum() - 1) < 1e-14 and abs(g["mu1"].sum() - 1) < 1e-14
+    assert np.allclose(g["vertices"].min(0), 0) and abs(g["vertices"].max() - 1) < 1e-14 and scale == pytest.approx(0.5)
+    assert meshes.icosphere(5)[0].shape[0] == 10242 and meshes.torus(400, 250)[0].shape[0] == 100000
