@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="sphere10k", choices=sorted(WORKLOADS))
     ap.add_argument("--lap-solver", default="modal_pcg", choices=["modal_pcg", "spacetime_pcg"])
+    ap.add_argument("--preconditioner", default="multigrid", choices=["multigrid", "jacobi"])
     ap.add_argument("--cg-tol", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-tol", action="store_true")
@@ -104,6 +105,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    # one rank per GPU; DOTS_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)
+    backend = os.environ.get("DOTS_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     from dots_socp_amd import meshes
@@ -120,14 +124,19 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        from dots_socp_amd.distributed import ShardedAlmSolver
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+        from dots_socp_amd.distributed import ShardedAlmSolver, TorchComm
 
-        alm = ShardedAlmSolver(n_time, geom, congestion=congestion, nit=args.warmup + args.steps + 8, tol=1e-30,
-                               cg_tol=cg_tol, device=local_rank)
+        alm = ShardedAlmSolver(n_time, geom, comm=TorchComm(), congestion=congestion, nit=args.warmup + args.steps + 8,
+                               tol=1e-30, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner,
+                               time_limit=float("inf"))
     else:
         alm = AlmSolver(n_time, geom, congestion=congestion, nit=args.warmup + args.steps + 8, tol=1e-30,
-                        lap_solver=args.lap_solver, cg_tol=cg_tol, device=local_rank)
+                        lap_solver=args.lap_solver, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner,
+                        time_limit=float("inf"))
 
     def barrier():
         alm.dev.sync()
@@ -165,6 +174,12 @@ def main():
                           "achieved": bytes_update / (ms_update * 1e-3) / 1e9, "algorithmic_bytes_per_launch": bytes_update},
         "working_set_note": "CG working set fits the 256 MiB Infinity Cache at this size" if V * (n_time + 1) * 8 * 6 < 256e6 else "",
     }
+    if getattr(alm, "mg_summary", None):
+        ms_vc, bytes_vc = alm.dev.bench_kernel(which=2, reps=100)
+        roofline["multigrid_vcycle"] = {
+            "ms_per_cycle": ms_vc, "finest_level_algorithmic_bytes": bytes_vc,
+            "achieved_finest_only": bytes_vc / (ms_vc * 1e-3) / 1e9, "hierarchy": alm.mg_summary,
+        }
     dev_bytes = alm.dev.device_bytes()
     alm.close()
 
@@ -172,7 +187,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_time_to_tol:
         t1 = time.perf_counter()
         solver = AlmSolver(n_time, geom, congestion=congestion, nit=20000, tol=tol, lap_solver=args.lap_solver, cg_tol=cg_tol,
-                           device=local_rank)
+                           device=local_rank, preconditioner=args.preconditioner)
         setup_s = time.perf_counter() - t1
         t1 = time.perf_counter()
         while not solver.iterate():
@@ -196,7 +211,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {wl['example']} mesh V={V} F={F}, ntime={n_time}, congestion={congestion}, "
-                        f"cg_tol={cg_tol:g}, lap_solver={args.lap_solver if world == 1 else 'modal_pcg (mode-sharded)'}",
+                        f"cg_tol={cg_tol:g}, lap_solver={args.lap_solver if world == 1 else 'modal_pcg (mode-sharded)'}, "
+                        f"preconditioner={args.preconditioner}",
             "unknowns": V * (n_time + 1), "state_bytes": 8 * ((n_time + 1) * V + 7 * n_time * V + 6 * (n_time + 1) * F + 36 * n_time * F),
             "device_bytes": dev_bytes, "pcg_iterations_per_step": cg_per_it,
             "step_seconds": steps_time,

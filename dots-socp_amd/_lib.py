@@ -27,6 +27,7 @@ EXPORTS = [
     "dots_sync", "dots_upload", "dots_download", "dots_array_count", "dots_step", "dots_run_phase", "dots_kkt",
     "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
+    "dots_step_begin", "dots_step_end", "dots_shard_elems",
 ]
 
 
@@ -46,6 +47,7 @@ class ProblemDesc(C.Structure):
         ("corner_ptr", _i32p), ("corner_idx", _i32p), ("lap_rowptr", _i32p), ("lap_col", _i32p), ("lap_val", _f64p),
         ("mu0", _f64p), ("mu1", _f64p), ("perm_vert", _i32p), ("perm_tri", _i32p),
         ("time_modes", _f64p), ("time_eigs", _f64p),
+        ("mode_begin", C.c_int32), ("mode_count", C.c_int32), ("mode_stride", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -133,13 +135,17 @@ def load():
     lib.dots_norm_square.argtypes = [vp, C.c_int, C.c_int, _f64p]
     lib.dots_apply_operator.argtypes = [vp, C.c_int, C.c_double, _f64p, C.c_int64, _f64p, C.c_int64]
     lib.dots_bench_kernel.argtypes = [vp, C.c_int, C.c_int, _f64p, _f64p]
+    lib.dots_step_begin.argtypes = [vp, vp, C.c_int64, C.POINTER(StepStats)]
+    lib.dots_step_end.argtypes = [vp, vp, C.c_int64, C.POINTER(StepStats)]
+    lib.dots_shard_elems.argtypes = [vp]
+    lib.dots_shard_elems.restype = C.c_int64
     lib.dots_mg_setup.argtypes = [vp, C.POINTER(MgDesc)]
     lib.dots_mg_enable.argtypes = [vp, C.c_int]
     lib.dots_device_bytes.argtypes = [vp]
     lib.dots_device_bytes.restype = C.c_int64
     for n in EXPORTS:
         f = getattr(lib, n)
-        if n not in ("dots_last_error", "dots_array_count", "dots_device_bytes"):
+        if n not in ("dots_last_error", "dots_array_count", "dots_device_bytes", "dots_shard_elems"):
             f.restype = C.c_int
     if lib.dots_abi_version() != ABI_VERSION:
         raise HipLibraryError("libdotsocp_hip.so ABI version mismatch; rebuild it")

@@ -148,9 +148,23 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     for (int id = 0; id < DOTS_N_ARRAYS; ++id)
         if ((rc = dev_alloc(c, state[id], array_count_device(d, id)))) return rc;
     const int64_t nnode = (int64_t)V << sh;
-    double **cgv[7] = {&d.cg_b, &d.cg_r, &d.cg_z, &d.cg_p0, &d.cg_p1, &d.cg_Ap, &d.cg_x};
-    for (auto q : cgv)
-        if ((rc = dev_alloc(c, q, nnode))) return rc;
+    const bool sharded = p->mode_count > 0 || p->mode_stride > 0;
+    if (sharded) {
+        if (p->lap_solver != DOTS_LAP_MODAL_PCG || p->mode_stride < 1 || p->mode_begin < 0 || p->mode_count < 0 ||
+            p->mode_begin + p->mode_count > d.T + 1 || p->mode_count > p->mode_stride) {
+            set_error("bad mode range (sharding needs the modal solver and 0 <= begin, count <= stride, begin+count <= T+1)");
+            return DOTS_ERR_ARGUMENT;
+        }
+        c->shard_begin = p->mode_begin;
+        c->shard_count = p->mode_count;
+        c->shard_stride = p->mode_stride;
+    }
+    if ((rc = dev_alloc(c, &d.cg_b, nnode))) return rc;
+    if (!sharded) {
+        double **cgv[6] = {&d.cg_r, &d.cg_z, &d.cg_p0, &d.cg_p1, &d.cg_Ap, &d.cg_x};
+        for (auto q : cgv)
+            if ((rc = dev_alloc(c, q, nnode))) return rc;
+    }
     const int gv = xcd_grid(d.n_vtiles), gf = xcd_grid(d.n_ftiles);
     const int64_t npart = std::max<int64_t>({(int64_t)MAX_SUMS * std::max(gv, gf) * 2, cg_partials_needed(d), 4096});
     if ((rc = dev_alloc(c, &d.partials, npart))) return rc;
@@ -160,6 +174,24 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     if ((rc = dev_alloc(c, &c->stage, c->stage_count))) return rc;
     DOTS_HIP(hipHostMalloc((void **)&c->h_pinned, sizeof(double) * CgScalOffsets::TOTAL, hipHostMallocDefault));
     DOTS_HIP(hipHostMalloc((void **)&c->h_flags, sizeof(int) * FLAG_TOTAL, hipHostMallocDefault));
+
+    // the PCG's view of the device data (see Ctx::dcg)
+    c->dcg = d;
+    if (sharded) {
+        Dev &g = c->dcg;
+        int tpl = 4, shl = 2;
+        while (tpl < p->mode_stride) { tpl <<= 1; ++shl; }
+        g.TP = tpl;
+        g.tp_shift = shl;
+        g.cg_ncol = p->mode_count;
+        std::vector<double> sig(tpl, 0.0);
+        for (int i = 0; i < p->mode_count; ++i) sig[i] = p->time_eigs[p->mode_begin + i];
+        if ((rc = dev_upload(c, &g.sigma, sig.data(), tpl))) return rc;
+        const int64_t nloc = (int64_t)V << shl;
+        double **cgv[6] = {&g.cg_r, &g.cg_z, &g.cg_p0, &g.cg_p1, &g.cg_Ap, &g.cg_x};
+        for (auto q : cgv)
+            if ((rc = dev_alloc(c, q, nloc))) return rc;
+    }
 
     // KKT normalisation constants (solver_socp.py:303-313): means of the broadcast weight arrays
     double sm = 0.0, sa = 0.0;
@@ -188,6 +220,44 @@ static int check(dots_ctx *ctx) {
     if (!ctx) { set_error("null context"); return DOTS_ERR_ARGUMENT; }
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
+    return 0;
+}
+
+// first half of an iteration: right-hand side + solve (for this context's modes)
+static int run_iteration_begin(Ctx *c, dots_step_stats *st) {
+    int rc;
+    DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
+    if ((rc = launch_rhs(c))) return rc;
+    DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
+    if ((rc = cg_solve(c, st))) return rc;
+    DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
+    DOTS_HIP(hipEventSynchronize(c->ev[2]));
+    if (st) {
+        float t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); st->ms_rhs += t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); st->ms_laplacian += t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[2])); st->ms_total += t;
+    }
+    return 0;
+}
+
+// second half (sharded contexts): phi from the gathered mode-space solutions, then steps 1-2, 2 and 3
+static int run_iteration_end(Ctx *c, const double *gathered, dots_step_stats *st) {
+    int rc;
+    DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
+    if ((rc = cg_finish_sharded(c, gathered))) return rc;
+    if ((rc = launch_soc_projection(c))) return rc;
+    DOTS_HIP(hipEventRecord(c->ev[3], c->stream));
+    if ((rc = launch_q_lambda_mult(c))) return rc;
+    DOTS_HIP(hipEventRecord(c->ev[4], c->stream));
+    DOTS_HIP(hipEventSynchronize(c->ev[4]));
+    if (st) {
+        float t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[3])); st->ms_soc += t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[3], c->ev[4])); st->ms_q_lambda_multiplier += t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[4])); st->ms_total += t;
+        st->alm_iterations += 1;
+    }
     return 0;
 }
 
@@ -232,8 +302,11 @@ static int mg_upload(Ctx *c, const T **out, const T *host, int64_t count) {
         return DOTS_ERR_STATE;
     }
     c->mg_allocs[c->n_mg_allocs++] = p;
-    if (host) DOTS_HIP(hipMemcpy(p, host, sizeof(T) * (size_t)count, hipMemcpyHostToDevice));
-    else DOTS_HIP(hipMemset(p, 0, bytes));
+    // on the context's own (non-blocking) stream: never touch the legacy default stream, another
+    // context of this process may be capturing a graph
+    if (host) DOTS_HIP(hipMemcpyAsync(p, host, sizeof(T) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    else DOTS_HIP(hipMemsetAsync(p, 0, bytes, c->stream));
+    DOTS_HIP(hipStreamSynchronize(c->stream));
     *out = (const T *)p;
     return 0;
 }
@@ -335,10 +408,45 @@ int dots_download(dots_ctx *c, int id, double *host, int64_t count) {
     return 0;
 }
 
+int64_t dots_shard_elems(dots_ctx *c) {
+    if (!c || c->shard_stride == 0) return -1;
+    return (int64_t)c->d.V << c->dcg.tp_shift;
+}
+
+int dots_step_begin(dots_ctx *c, double *send, int64_t count, dots_step_stats *stats) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (c->shard_stride == 0) { set_error("step_begin: context is not sharded"); return DOTS_ERR_STATE; }
+    if (!send || count != dots_shard_elems(c)) { set_error("step_begin: bad send buffer"); return DOTS_ERR_ARGUMENT; }
+    dots_step_stats local;
+    memset(&local, 0, sizeof local);
+    if ((rc = run_iteration_begin(c, &local))) return rc;
+    if (c->dcg.cg_ncol > 0) DOTS_HIP(hipMemcpyAsync(send, c->dcg.cg_x, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, c->stream));
+    else DOTS_HIP(hipMemsetAsync(send, 0, sizeof(double) * (size_t)count, c->stream));
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    if (stats) *stats = local;
+    return 0;
+}
+
+int dots_step_end(dots_ctx *c, const double *recv, int64_t count, dots_step_stats *stats) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (c->shard_stride == 0) { set_error("step_end: context is not sharded"); return DOTS_ERR_STATE; }
+    const int n_ranks = (c->d.T + 1 + c->shard_stride - 1) / c->shard_stride;
+    const int64_t elems = dots_shard_elems(c);
+    if (!recv || count < n_ranks * elems || count % elems != 0) { set_error("step_end: bad receive buffer (need >= n_ranks chunks of shard_elems doubles)"); return DOTS_ERR_ARGUMENT; }
+    dots_step_stats local;
+    memset(&local, 0, sizeof local);
+    if ((rc = run_iteration_end(c, recv, &local))) return rc;
+    if (stats) *stats = local;
+    return 0;
+}
+
 int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
     int rc = check(c);
     if (rc) return rc;
     if (n_iters < 0) { set_error("n_iters < 0"); return DOTS_ERR_ARGUMENT; }
+    if (c->shard_stride != 0) { set_error("dots_step on a sharded context: use dots_step_begin / dots_step_end"); return DOTS_ERR_STATE; }
     dots_step_stats local;
     memset(&local, 0, sizeof local);
     for (int i = 0; i < n_iters; ++i)
@@ -464,11 +572,11 @@ int dots_mg_setup(dots_ctx *c, const dots_mg_desc *m) {
     if (rc) return rc;
     if (!m || m->n_levels < 2 || m->n_levels > 10 || !m->levels || !m->coarse_inverse) { set_error("mg_setup: bad description"); return DOTS_ERR_ARGUMENT; }
     if (c->lap_solver != DOTS_LAP_MODAL_PCG) { set_error("multigrid needs the modal solver"); return DOTS_ERR_ARGUMENT; }
-    if (m->levels[0].n != c->d.V || m->n_cols != c->d.cg_ncol) { set_error("mg_setup: level 0 / mode count mismatch"); return DOTS_ERR_ARGUMENT; }
+    if (m->levels[0].n != c->d.V || m->n_cols != c->dcg.cg_ncol) { set_error("mg_setup: level 0 / mode count mismatch"); return DOTS_ERR_ARGUMENT; }
     DOTS_HIP(hipStreamSynchronize(c->stream));
     if (c->cg_graph) { (void)hipGraphExecDestroy(c->cg_graph); c->cg_graph = nullptr; }
     mg_release(c);
-    const Dev &d = c->d;
+    const Dev &d = c->dcg;   // level vectors and the coarse inverse use the PCG view's pitch
     MgDev g{};
     g.nlev = m->n_levels;
     g.omega = m->omega;

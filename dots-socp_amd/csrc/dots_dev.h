@@ -119,6 +119,7 @@ int launch_from_device_layout(Ctx *c, int array_id, double *staged);
 int launch_operator(Ctx *c, int op, double scale, const double *in_staged, double *out_staged);
 int cg_solve(Ctx *c, dots_step_stats *stats);
 int cg_apply_operator(Ctx *c, const double *x_node, double *y_node);  // y = K x in node layout
+int cg_finish_sharded(Ctx *c, const double *gathered);                // phi from all ranks' mode-space solutions
 int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes);
 int64_t cg_partials_needed(const Dev &d);   // doubles of Dev::partials the PCG uses
 int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int ept, int vt, int G);  // enqueue z = MG(r); z holds D^-1 r on entry
@@ -129,6 +130,12 @@ int reduce_partials(Ctx *c, const double *partials, int n_slots, int n_blocks, i
 
 struct Ctx {
     Dev d{};
+    // The PCG's view of the device data.  Identical to `d` on one GPU.  When the time modes are sharded
+    // over ranks it has this rank's column count, its own (smaller) pitch, PCG vectors and sigma slice.
+    Dev dcg{};
+    int shard_begin = 0;    // first time mode of this context
+    int shard_count = 0;    // modes of this context; 0 = not sharded (all T+1)
+    int shard_stride = 0;   // modes per rank (same on every rank) = layout of the gathered buffer
     dots_params prm{};
     int device = 0;
     int lap_solver = 0;

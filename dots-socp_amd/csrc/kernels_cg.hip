@@ -408,7 +408,7 @@ static void cg_tiling(const Dev &d, int *ept_out, int *vt_out, int *G_out) {
 }
 
 static CgArgs make_args(Ctx *c, bool modal) {
-    const Dev &d = c->d;
+    const Dev &d = modal ? c->dcg : c->d;
     CgArgs a{};
     cg_tiling(d, &a.ept, &a.vt, &a.G);
     a.cap = a.vt * 12 + 64;          // ~7 entries per row on a triangle mesh; entries beyond cap are read from global
@@ -430,7 +430,7 @@ int64_t cg_partials_needed(const Dev &d) {
 
 template <bool MODAL>
 static int cg_iterations(Ctx *c, CgArgs a, double *x, int n_iter) {
-    const Dev &d = c->d;
+    const Dev &d = MODAL ? c->dcg : c->d;
     const size_t lds = cg_lds_bytes(a.cap, a.vt);
     for (int it = 0; it < n_iter; ++it) {
         const bool odd = (it & 1) != 0;
@@ -479,7 +479,7 @@ static int cg_graph_prepare(Ctx *c, const CgArgs &a, double *x, int unit) {
 // PCG on the node-layout right-hand side b (already in mode space when MODAL), solution in x.
 template <bool MODAL>
 static int cg_core(Ctx *c, const double *b, double *x, dots_step_stats *stats) {
-    const Dev &d = c->d;
+    const Dev &d = MODAL ? c->dcg : c->d;
     CgArgs a = make_args(c, MODAL);
     const size_t lds = cg_lds_bytes(a.cap, a.vt);
     a.zin = x;
@@ -528,25 +528,84 @@ static int cg_core(Ctx *c, const double *b, double *x, dots_step_stats *stats) {
     return 0;
 }
 
+// Forward time-mode transform restricted to the modes [a0, a0 + dcg.cg_ncol) this context solves, written
+// with the PCG view's own pitch:  y[v][j] = sum_t Q[t][a0 + j] x[v][t].   Emits the column-0 partial sums
+// (mean removal of the singular mode) when asked to.
+__global__ __launch_bounds__(BLOCK) void k_time_modes_fwd_sub(Dev d, Dev g, int a0, const double *__restrict__ x, double *__restrict__ y,
+                                                            int emit_col0) {
+    __shared__ double lds[4];
+    const int n = d.T + 1, nloc = g.cg_ncol;
+    double part[1] = {0.0};
+    const int64_t total = (int64_t)d.V << g.tp_shift;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int v = (int)(e >> g.tp_shift), j = (int)(e & (g.TP - 1));
+        if (j >= nloc) continue;
+        const double *row = x + idxV(d, v, 0);
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += d.Q[i * n + a0 + j] * row[i];
+        y[idxV(g, v, j)] = s;
+        if (emit_col0 && j == 0) part[0] += s;
+    }
+    if (emit_col0) {
+        block_sum<1>(part, lds);
+        if (threadIdx.x == 0) d.partials[blockIdx.x] = part[0];
+    }
+}
+
+// Inverse transform from the gathered mode-space solution of all ranks: gathered[p][v][j] holds mode
+// p * nloc + j with pitch tpl.   phi[v][t] = sum_a Q[t][a] xhat[a][v]
+__global__ __launch_bounds__(BLOCK) void k_time_modes_inv_gathered(Dev d, const double *__restrict__ gathered, int nloc, int tpl_shift,
+                                                                 double *__restrict__ y) {
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    const int n = d.T + 1;
+    if (tile >= d.n_vtiles) return;
+    const int64_t rank_stride = (int64_t)d.V << tpl_shift;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (v >= d.V || t >= n) continue;
+        double s = 0.0;
+        for (int a = 0; a < n; ++a) {
+            const int p = a / nloc, j = a - p * nloc;
+            s += d.Q[t * n + a] * gathered[p * rank_stride + ((int64_t)v << tpl_shift) + j];
+        }
+        y[idxV(d, v, t)] = s;
+    }
+}
+
+// Step 1 for the modes of this context.  Unsharded: also transforms back (phi is complete on return).
+// Sharded: the local mode-space solution stays in dcg.cg_x for the caller to exchange (cg_finish_sharded).
 template <bool MODAL>
 static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
     const Dev &d = c->d;
+    const Dev &g = c->dcg;
     const int gt = xcd_grid(d.n_vtiles);
     const bool singular = (c->prm.eps == 0.0);
-    double *x = MODAL ? d.cg_x : d.phi;
+    double *x = MODAL ? g.cg_x : d.phi;
     const double *b = d.cg_b;
-    if (MODAL) {
-        // b^ = Q^T b (into p0 as scratch), x^ = Q^T phi (warm start in mode space)
-        hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_b, d.cg_p0, 1);
-        hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.phi, d.cg_x, 0);
-        b = d.cg_p0;   // consumed by k_cg_r0 before iteration 0 (which reads no p_old: beta = 0) writes p1
+    const bool sharded = MODAL && c->shard_count > 0;
+    const bool owns_mode0 = !sharded || c->shard_begin == 0;
+    if (MODAL && g.cg_ncol == 0) return 0;   // a rank without modes has nothing to solve
+    if (sharded) {
+        const int gs = 1024;   // grid-stride; k_cg_bmean sums exactly this many partial sums
+        hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.cg_b, g.cg_p0, owns_mode0 ? 1 : 0);
+        hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.phi, g.cg_x, 0);
+        b = g.cg_p0;
+        const double mean_scale = (singular && owns_mode0) ? 1.0 / d.V : 0.0;
+        hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, owns_mode0 ? gs : 0, g.cg_ncol, mean_scale);
+    } else {
+        if (MODAL) {
+            // b^ = Q^T b (into p0 as scratch), x^ = Q^T phi (warm start in mode space)
+            hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_b, d.cg_p0, 1);
+            hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.phi, d.cg_x, 0);
+            b = d.cg_p0;   // consumed by k_cg_r0 before iteration 0 (which reads no p_old: beta = 0) writes p1
+        }
+        const double mean_scale = !singular ? 0.0 : (MODAL ? 1.0 / d.V : 1.0 / ((double)d.V * (d.T + 1)));
+        hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, gt, MODAL ? d.cg_ncol : 1, mean_scale);
     }
-    const double mean_scale = !singular ? 0.0 : (MODAL ? 1.0 / d.V : 1.0 / ((double)d.V * (d.T + 1)));
-    hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, gt, MODAL ? d.cg_ncol : 1, mean_scale);
     DOTS_HIP(hipGetLastError());
     int rc = cg_core<MODAL>(c, b, x, stats);
     if (rc) return rc;
-    if (MODAL) {
+    if (MODAL && !sharded) {
         hipLaunchKernelGGL((k_time_modes<false>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_x, d.phi, 0);
         DOTS_HIP(hipGetLastError());
     }
@@ -555,6 +614,15 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
 
 int cg_solve(Ctx *c, dots_step_stats *stats) {
     return c->lap_solver == DOTS_LAP_MODAL_PCG ? cg_solve_impl<true>(c, stats) : cg_solve_impl<false>(c, stats);
+}
+
+// phi from the mode-space solutions of all ranks (device buffer [n_ranks][V][local pitch])
+int cg_finish_sharded(Ctx *c, const double *gathered) {
+    const Dev &d = c->d;
+    hipLaunchKernelGGL(k_time_modes_inv_gathered, dim3(xcd_grid(d.n_vtiles)), dim3(BLOCK), 0, c->stream, d, gathered, c->shard_stride,
+                       c->dcg.tp_shift, d.phi);
+    DOTS_HIP(hipGetLastError());
+    return 0;
 }
 
 // y = K x on node-layout arrays with the coupled space-time operator (tests, operator parity)
@@ -570,8 +638,8 @@ int cg_apply_operator(Ctx *c, const double *x, double *y) {
 // Time `reps` launches of one PCG kernel between two hipEvents.
 //   which 0: k_cg_apply (fused direction update + operator + p.Ap)     1: k_cg_update     2: one multigrid V-cycle
 int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes) {
-    const Dev &d = c->d;
     const bool modal = c->lap_solver == DOTS_LAP_MODAL_PCG;
+    const Dev &d = modal ? c->dcg : c->d;
     CgArgs a = make_args(c, modal);
     const size_t lds = cg_lds_bytes(a.cap, a.vt);
     if (which == 2 && !a.mg) {

@@ -170,7 +170,7 @@ static inline int mg_grid(const Dev &d, int rows) { return (int)((((int64_t)rows
 // Enqueue one V-cycle.  r: residual; z: holds D^-1 r on entry (written by the PCG update kernel) and the
 // preconditioned residual on exit; r.z partial sums go to `rz_part`.  Level 0 uses `t0` as scratch.
 int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int ept, int vt, int G) {
-    const Dev &d = c->d;
+    const Dev &d = c->dcg;   // the PCG's view: its own column range, pitch and sigma
     const MgDev &m = c->mg;
     MgArgs a{c->prm.eps, m.omega, d.cg_ncol};
     const int nl = m.nlev;

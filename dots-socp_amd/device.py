@@ -21,7 +21,10 @@ def _ptr(a, ctype):
 
 
 class DeviceProblem:
-    def __init__(self, n_time, geometry, lap_solver="spacetime_pcg", device=0, reorder=True, plan: DevicePlan | None = None):
+    def __init__(self, n_time, geometry, lap_solver="spacetime_pcg", device=0, reorder=True, plan: DevicePlan | None = None,
+                 mode_shard=None):
+        """``mode_shard = (rank, n_ranks)``: this context solves only its slice of the T+1 time modes
+        (multi-GPU, see distributed.py); the caller then drives ``step_begin`` / ``step_end``."""
         self.lib = _lib.load()
         self.plan = plan if plan is not None else build_plan(n_time, geometry, reorder=reorder)
         p = self.plan
@@ -51,6 +54,15 @@ class DeviceProblem:
         d.perm_tri = _ptr(p.perm_tri, C.c_int32)
         d.time_modes = _ptr(p.time_modes, C.c_double)
         d.time_eigs = _ptr(p.time_eigs, C.c_double)
+        self.mode_slice = None
+        if mode_shard is not None:
+            rank, n_ranks = mode_shard
+            stride = -(-(p.n_time + 1) // n_ranks)
+            begin = min(rank * stride, p.n_time + 1)
+            count = max(0, min(stride, p.n_time + 1 - begin))
+            d.mode_begin, d.mode_count, d.mode_stride = begin, count, stride
+            self.mode_slice = slice(begin, begin + count)
+            self.mode_stride, self.n_ranks = stride, n_ranks
         self._h = C.c_void_p()
         _lib.check(self.lib.dots_create(C.byref(d), C.byref(self._h)), "dots_create")
         self.params = _lib.Params()
@@ -112,6 +124,22 @@ class DeviceProblem:
     def step(self, n_iters=1):
         st = _lib.StepStats()
         _lib.check(self.lib.dots_step(self._h, int(n_iters), C.byref(st)), "dots_step")
+        return st
+
+    # ---- sharded iteration (multi-GPU): begin -> all-gather by the caller -> end
+    def shard_elems(self):
+        return int(self.lib.dots_shard_elems(self._h))
+
+    def step_begin(self, send_ptr, count):
+        """Right-hand side + PCG for this context's modes; the result is copied to device memory at send_ptr."""
+        st = _lib.StepStats()
+        _lib.check(self.lib.dots_step_begin(self._h, C.c_void_p(int(send_ptr)), int(count), C.byref(st)), "dots_step_begin")
+        return st
+
+    def step_end(self, recv_ptr, count):
+        """Inverse time transform from the gathered buffer at recv_ptr, then steps 1-2, 2 and 3."""
+        st = _lib.StepStats()
+        _lib.check(self.lib.dots_step_end(self._h, C.c_void_p(int(recv_ptr)), int(count), C.byref(st)), "dots_step_end")
         return st
 
     def run_phase(self, phase):
@@ -189,7 +217,11 @@ class DeviceProblem:
         levels = multigrid.build_hierarchy(K, p.mass_vert, coarsest=coarsest)
         if len(levels) < 2:
             return None
+        if mode_slice is None:
+            mode_slice = self.mode_slice
         sigma = p.time_eigs if mode_slice is None else p.time_eigs[mode_slice]
+        if sigma.size == 0:
+            return None      # a rank without modes solves nothing
         last = levels[-1]
         inv = np.empty((last.n, last.n, sigma.size))
         for k, s in enumerate(sigma):

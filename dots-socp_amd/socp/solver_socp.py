@@ -63,13 +63,14 @@ class AlmSolver:
     def __init__(self, n_time, geometry, congestion=0.0, nit=1000, eps=0.0, tol=1e-4, tau=1.90, is_z_scaling=True,
                  is_constant_scaling=False, check_kkt_step_by_step=False, init_solution=None, tol_checkpoints=None,
                  time_limit=1000, lap_solver="modal_pcg", cg_tol=DEFAULT_CG_TOL, cg_max_iter=20000, device=0, reorder=True,
-                 preconditioner="multigrid", mg_coarsest=96):
+                 preconditioner="multigrid", mg_coarsest=96, mode_shard=None):
         self.tol_checkpoints = _validate_checkpoints(tol_checkpoints, tol)
         self.checkpoint_solutions = []
         self.n_time, self.nit, self.tol, self.time_limit = int(n_time), int(nit), tol, time_limit
         self.is_z_scaling, self.is_constant_scaling = is_z_scaling, is_constant_scaling
         self.check_kkt_step_by_step = check_kkt_step_by_step
-        self.dev = dev = DeviceProblem(n_time, geometry, lap_solver=lap_solver, device=device, reorder=reorder)
+        self.dev = dev = DeviceProblem(n_time, geometry, lap_solver=lap_solver, device=device, reorder=reorder,
+                                       mode_shard=mode_shard)
 
         p = dev.params
         self.r = 1.0
@@ -216,6 +217,21 @@ class AlmSolver:
             return (self.r * self.dual_scale) * arr
         return (self.r * self.scale_z * self.dual_scale) * arr
 
+    def _device_step(self):
+        """Steps 1-3 on the device; the multi-GPU solver overrides this with begin / all-gather / end."""
+        self._account(self.dev.step(1))
+
+    def _time_is_up(self):
+        return (time.perf_counter() - self.start_time) > self.time_limit
+
+    def _account(self, st):
+        hist = self.run_history
+        self.cg_total += st.cg_iterations
+        self.cg_fail += st.cg_not_converged
+        hist.add_time("Step 1-1 (Laplacian)", 1e-3 * (st.ms_rhs + st.ms_laplacian))
+        hist.add_time("Step 1-2 (SOC-Projection)", 1e-3 * st.ms_soc)
+        hist.add_time("Step 2+3 (Q & Lambda, Multiplier)", 1e-3 * st.ms_q_lambda_multiplier)
+
     # ---- one pass of the main loop (:656-823); returns True when the loop must stop ------------
     def iterate(self):
         if self.finished:
@@ -229,14 +245,9 @@ class AlmSolver:
             if rescale_z > 1.25:
                 self.scale_variable_z(rescale_z, msg=f"Rescale z at iteration {it}")
 
-        st = dev.step(1)                                                        # steps 1-3 (:674-722)
-        self.cg_total += st.cg_iterations
-        self.cg_fail += st.cg_not_converged
-        hist.add_time("Step 1-1 (Laplacian)", 1e-3 * (st.ms_rhs + st.ms_laplacian))
-        hist.add_time("Step 1-2 (SOC-Projection)", 1e-3 * st.ms_soc)
-        hist.add_time("Step 2+3 (Q & Lambda, Multiplier)", 1e-3 * st.ms_q_lambda_multiplier)
+        self._device_step()                                                     # steps 1-3 (:674-722)
 
-        is_time_used_up = (time.perf_counter() - self.start_time) > self.time_limit
+        is_time_used_up = self._time_is_up()
         adjust = params.is_to_adjust(it) or is_time_used_up
         required = KKT_PRIM + KKT_DUAL if adjust else None
         validator = self.kkt_validator

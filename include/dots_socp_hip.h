@@ -92,6 +92,13 @@ typedef struct dots_problem_desc {
     const double *time_modes;    /* [(T+1)*(T+1)] row-major Q[t][a]: orthonormal eigenvectors of the Neumann
                                     time Laplacian (laplacian_inverse_socp.py:15-31); NULL unless MODAL */
     const double *time_eigs;     /* [T+1] eigenvalues sigma_a >= 0 of -L_time;  NULL unless MODAL */
+    /* Multi-GPU (one context per rank): the time modes [mode_begin, mode_begin + mode_count) are solved
+     * by this context; mode_stride = modes per rank (ceil((T+1)/n_ranks), the same on every rank).
+     * All zero = single GPU, every mode.  See dots_step_begin / dots_step_end. */
+    int32_t mode_begin;
+    int32_t mode_count;
+    int32_t mode_stride;
+    int32_t reserved;
 } dots_problem_desc;
 
 /* Scalars the host control logic owns (solver_socp.py:97,318-321 and the kwargs of :25-41). */
@@ -145,6 +152,19 @@ int64_t dots_array_count(dots_ctx *ctx, int array_id);
 /* ---- the hot loop ------------------------------------------------------------------------ */
 /* n ALM iterations, steps 1-3 of solver_socp.py:674-722 (is_palm = False), device resident. */
 int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
+
+/* One ALM iteration split around the only exchange of the multi-GPU path (mode-sharded solve):
+ *   dots_step_begin  right-hand side + PCG for this context's time modes; the mode-space solution
+ *                    [V][pitch] (dots_shard_elems doubles) is copied to the DEVICE buffer `send`
+ *   (caller)         all-gather of `send` over the ranks into `recv` = [n_ranks][V][pitch]  (RCCL)
+ *   dots_step_end    inverse time transform from `recv`, then the cone projection and the
+ *                    (q, lambda) + multiplier update
+ * Both calls are synchronous with respect to the host (the context's stream is drained on return), so
+ * the caller may hand the buffers to another stream/library.  Every rank holds the complete ALM state
+ * (the element-wise steps are replicated, the solve is not): results are bit-identical on all ranks. */
+int dots_step_begin(dots_ctx *ctx, double *send, int64_t count, dots_step_stats *stats);
+int dots_step_end(dots_ctx *ctx, const double *recv, int64_t count, dots_step_stats *stats);
+int64_t dots_shard_elems(dots_ctx *ctx);   /* doubles one rank contributes: V * pitch;  -1 if not sharded */
 
 /* single phases of one iteration, for per-function parity tests */
 enum dots_phase {
