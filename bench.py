@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--cg-tol", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-tol", action="store_true")
+    ap.add_argument("--no-reorder", action="store_true", help="keep the generator's vertex numbering (A/B of the RCM renumbering)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -132,11 +133,11 @@ def main():
 
         alm = ShardedAlmSolver(n_time, geom, comm=TorchComm(), congestion=congestion, nit=args.warmup + args.steps + 8,
                                tol=1e-30, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner,
-                               time_limit=float("inf"))
+                               time_limit=float("inf"), reorder=not args.no_reorder)
     else:
         alm = AlmSolver(n_time, geom, congestion=congestion, nit=args.warmup + args.steps + 8, tol=1e-30,
                         lap_solver=args.lap_solver, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner,
-                        time_limit=float("inf"))
+                        time_limit=float("inf"), reorder=not args.no_reorder)
 
     def barrier():
         alm.dev.sync()
@@ -187,7 +188,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_time_to_tol:
         t1 = time.perf_counter()
         solver = AlmSolver(n_time, geom, congestion=congestion, nit=20000, tol=tol, lap_solver=args.lap_solver, cg_tol=cg_tol,
-                           device=local_rank, preconditioner=args.preconditioner)
+                           device=local_rank, preconditioner=args.preconditioner, reorder=not args.no_reorder)
         setup_s = time.perf_counter() - t1
         t1 = time.perf_counter()
         while not solver.iterate():

@@ -66,7 +66,7 @@ class MgLevel(C.Structure):
         ("diag_k", _f64p), ("diag_m", _f64p), ("n_coarse", C.c_int32), ("p_nnz", C.c_int32),
         ("p_rowptr", _i32p), ("p_col", _i32p), ("p_val", _f64p), ("r_rowptr", _i32p), ("r_col", _i32p), ("r_val", _f64p),
         ("ap_nnz", C.c_int32), ("reserved", C.c_int32), ("ap_rowptr", _i32p), ("ap_col", _i32p),
-        ("ap_val_k", _f64p), ("ap_val_m", _f64p),
+        ("ap_val_k", _f64p), ("ap_val_m", _f64p), ("ap_val_p", _f64p),
     ]
 
 

@@ -607,9 +607,9 @@ int dots_mg_setup(dots_ctx *c, const dots_mg_desc *m) {
         if (l + 1 < m->n_levels) {
             MUP(p_rp, h.p_rowptr, h.n + 1); MUP(p_col, h.p_col, h.p_nnz); MUP(p_val, h.p_val, h.p_nnz);
             MUP(r_rp, h.r_rowptr, h.n_coarse + 1); MUP(r_col, h.r_col, h.p_nnz); MUP(r_val, h.r_val, h.p_nnz);
-            if (!h.ap_rowptr || !h.ap_col || !h.ap_val_k || !h.ap_val_m || h.ap_rowptr[h.n] != h.ap_nnz) { set_error("mg_setup: bad A*P arrays"); mg_release(c); return DOTS_ERR_ARGUMENT; }
+            if (!h.ap_rowptr || !h.ap_col || !h.ap_val_k || !h.ap_val_m || !h.ap_val_p || h.ap_rowptr[h.n] != h.ap_nnz) { set_error("mg_setup: bad A*P arrays"); mg_release(c); return DOTS_ERR_ARGUMENT; }
             for (int j = 0; j < h.ap_nnz; ++j) if (h.ap_col[j] < 0 || h.ap_col[j] >= h.n_coarse) { set_error("mg_setup: A*P index out of range"); mg_release(c); return DOTS_ERR_ARGUMENT; }
-            MUP(ap_rp, h.ap_rowptr, h.n + 1); MUP(ap_col, h.ap_col, h.ap_nnz); MUP(ap_vK, h.ap_val_k, h.ap_nnz); MUP(ap_vM, h.ap_val_m, h.ap_nnz);
+            MUP(ap_rp, h.ap_rowptr, h.n + 1); MUP(ap_col, h.ap_col, h.ap_nnz); MUP(ap_vK, h.ap_val_k, h.ap_nnz); MUP(ap_vM, h.ap_val_m, h.ap_nnz); MUP(ap_vP, h.ap_val_p, h.ap_nnz);
         }
 #undef MUP
         // level vectors; level 0 works on the PCG's own r, z and Ap buffers

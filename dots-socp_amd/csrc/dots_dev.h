@@ -79,8 +79,8 @@ struct MgLevelDev {
     const int *r_rp, *r_col;                 // R = P^T: nc x n
     const double *r_val;
     const int *ap_rp, *ap_col;               // A P = K P + s M P: n x nc, two value arrays on one pattern
-    const double *ap_vK, *ap_vM;
-    double *b, *bt, *t;                      // level vectors [n][TP] (level 0 borrows the PCG's r, z, Ap)
+    const double *ap_vK, *ap_vM, *ap_vP;     // ap_vP: P itself on the pattern of A P (zeros where absent)
+    double *b, *bt, *t;                      // level vectors [n][TP]: rhs, D^-1 rhs / result, residual (level 0 borrows the PCG's r, z, Ap)
 };
 struct MgDev {
     int nlev = 0;
@@ -122,7 +122,7 @@ int cg_apply_operator(Ctx *c, const double *x_node, double *y_node);  // y = K x
 int cg_finish_sharded(Ctx *c, const double *gathered);                // phi from all ranks' mode-space solutions
 int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes);
 int64_t cg_partials_needed(const Dev &d);   // doubles of Dev::partials the PCG uses
-int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int ept, int vt, int G);  // enqueue z = MG(r); z holds D^-1 r on entry
+int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int nb, int ept, int vt, int G);  // enqueue z = MG(r); z holds D^-1 r on entry
 int kkt_evaluate(Ctx *c, uint32_t mask, double *out);
 int objective_evaluate(Ctx *c, double *out);
 int norm_square(Ctx *c, int array_id, int part, double *out);

@@ -31,12 +31,14 @@
 // Stopping rule (both preconditioners): r^T D^-1 r <= cg_tol^2 * b^T D^-1 b with D = diag(K).
 #include "dots_dev.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace dots {
 
 using S = CgScalOffsets;
-constexpr int CG_NB = 1024;          // threads per workgroup of the PCG kernels (16 wave64)
+constexpr int CG_NB = 1024;          // largest workgroup of the PCG kernels (16 wave64); large problems use CG_NB_LARGE
+constexpr int CG_NB_LARGE = 256;
 
 template <bool MODAL>
 __device__ __forceinline__ double shift_of(const Dev &d, int t) {
@@ -49,30 +51,36 @@ __device__ __forceinline__ int n_cols(const Dev &d) { return MODAL ? d.cg_ncol :
 // Dynamic LDS carve-up of the PCG kernels.
 struct CgLds {
     double *val;    // [cap]   staged CSR values
-    double *red;    // [CG_NB] reduction scratch
-    double *tot;    // [CG_NB] column totals / broadcast
+    double *red;    // [blockDim] reduction scratch
+    double *tot;    // [blockDim] column totals / broadcast
     int *col;       // [cap]
     int *rp;        // [VT + 2]
 };
 __device__ __forceinline__ CgLds carve(unsigned char *base, int cap) {
     CgLds l;
+    const int nb = blockDim.x;
     l.val = reinterpret_cast<double *>(base);
     l.red = l.val + cap;
-    l.tot = l.red + CG_NB;
-    l.col = reinterpret_cast<int *>(l.tot + CG_NB);
+    l.tot = l.red + nb;
+    l.col = reinterpret_cast<int *>(l.tot + nb);
     l.rp = l.col + cap;
     return l;
 }
-static size_t cg_lds_bytes(int cap, int vt) { return sizeof(double) * ((size_t)cap + 2 * CG_NB) + sizeof(int) * ((size_t)cap + vt + 2); }
+static size_t cg_lds_bytes(int cap, int vt, int nb) { return sizeof(double) * ((size_t)cap + 2 * nb) + sizeof(int) * ((size_t)cap + vt + 2); }
 
 // Sum over workgroups of a partial array part[G][TP] (column fastest: one coalesced row per workgroup)
 // for the column of the calling thread (MODAL: c = tid & (TP-1); otherwise the single column 0).
 template <bool MODAL>
 __device__ __forceinline__ double column_total(const Dev &d, const double *part, int G, const CgLds &l) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NB = blockDim.x;
+    if (G == 1) {   // already collapsed by k_collapse: one row, no reduction and no barrier
+        if (!MODAL) return part[0];
+        const int c = tid & (d.TP - 1);
+        return c < d.cg_ncol ? part[c] : 0.0;
+    }
     double s = 0.0;
     if (MODAL) {
-        const int c = tid & (d.TP - 1), j = tid >> d.tp_shift, J = CG_NB >> d.tp_shift;
+        const int c = tid & (d.TP - 1), j = tid >> d.tp_shift, J = NB >> d.tp_shift;
         if (c < d.cg_ncol)
             for (int g = j; g < G; g += J) s += part[((int64_t)g << d.tp_shift) + c];
         l.red[tid] = s;
@@ -87,13 +95,13 @@ __device__ __forceinline__ double column_total(const Dev &d, const double *part,
         __syncthreads();
         return out;
     } else {
-        for (int g = tid; g < G; g += CG_NB) s += part[g];
+        for (int g = tid; g < G; g += NB) s += part[g];
         s = wave_sum(s);
         if ((tid & 63) == 0) l.red[tid >> 6] = s;
         __syncthreads();
         if (tid == 0) {
             double t = 0.0;
-            for (int k = 0; k < CG_NB / 64; ++k) t += l.red[k];
+            for (int k = 0; k < NB / 64; ++k) t += l.red[k];
             l.tot[0] = t;
         }
         __syncthreads();
@@ -106,9 +114,23 @@ __device__ __forceinline__ double column_total(const Dev &d, const double *part,
 // Emit the per-workgroup partial sum(s) of one value per thread into part[G][TP] (fixed order).
 template <bool MODAL>
 __device__ __forceinline__ void emit_partial(const Dev &d, double acc, double *part, const CgLds &l) {
-    const int tid = threadIdx.x;
-    if (MODAL) {
-        const int c = tid & (d.TP - 1), j = tid >> d.tp_shift, J = CG_NB >> d.tp_shift;
+    const int tid = threadIdx.x, NB = blockDim.x;
+    if (MODAL && d.TP <= 64) {
+        // lanes of a wave that share a column are TP apart: fold them with xor-shuffles, then one LDS
+        // slot per (wave, column) and a single barrier
+        double s = acc;
+        for (int o = 32; o >= d.TP; o >>= 1) s += __shfl_xor(s, o, 64);
+        const int lane = tid & 63, w = tid >> 6, nw = NB >> 6;
+        if (lane < d.TP) l.red[w * d.TP + lane] = s;
+        __syncthreads();
+        if (tid < d.cg_ncol) {
+            double t = 0.0;
+            for (int k = 0; k < nw; ++k) t += l.red[k * d.TP + tid];
+            part[((int64_t)blockIdx.x << d.tp_shift) + tid] = t;
+        }
+        __syncthreads();
+    } else if (MODAL) {
+        const int c = tid & (d.TP - 1), j = tid >> d.tp_shift, J = NB >> d.tp_shift;
         l.red[tid] = acc;
         __syncthreads();
         if (j == 0 && c < d.cg_ncol) {
@@ -123,7 +145,7 @@ __device__ __forceinline__ void emit_partial(const Dev &d, double acc, double *p
         __syncthreads();
         if (tid == 0) {
             double t = 0.0;
-            for (int k = 0; k < CG_NB / 64; ++k) t += l.red[k];
+            for (int k = 0; k < NB / 64; ++k) t += l.red[k];
             part[blockIdx.x] = t;
         }
         __syncthreads();
@@ -139,23 +161,34 @@ struct CgArgs {
     double eps, tol2;
     int parity;            // which r.z buffer this iteration reads
     int ept;               // elements per thread
-    int vt;                // vertices per tile = CG_NB * ept / TP
+    int nb;                // threads per workgroup (1024, or 256 for large problems)
+    int vt;                // vertices per tile = nb * ept / TP
     int cap;               // staged CSR capacity
     int G;                 // workgroups (= tiles, padded to a multiple of 8)
     int nc;                // scalar columns
     int pstride;           // doubles per partial array = G * TP (MODAL) or G
     int stage;             // 1: stage the CSR row block in LDS, 0: read it through L1
     int mg;                // 1: z comes from the multigrid V-cycle (r.z and the stopping norm are separate sums)
+    int collapse;          // 1: a small kernel sums the G partial rows once and consumers read that single row
+    int Gr;                // rows a consumer re-reduces: G, or 1 when collapsed
+    int prow;              // doubles per partial row: TP (MODAL) or 1
 };
 
-// offsets into Dev::partials for the PCG: r.z (two parities), p.Ap, bref, stopping norm (two parities)
-__device__ __host__ __forceinline__ int64_t part_rz(const CgArgs &a, int parity) { return (int64_t)parity * a.pstride; }
-__device__ __host__ __forceinline__ int64_t part_pap(const CgArgs &a) { return (int64_t)2 * a.pstride; }
-__device__ __host__ __forceinline__ int64_t part_bref(const CgArgs &a) { return (int64_t)3 * a.pstride; }
-__device__ __host__ __forceinline__ int64_t part_crit(const CgArgs &a, int parity) {
-    return a.mg ? (int64_t)(4 + parity) * a.pstride : part_rz(a, parity);
-}
+// Partial-sum arrays of the PCG in Dev::partials: r.z (two parities), p.Ap, bref, stopping norm (two
+// parities), G rows each; behind them one collapsed row per array (used when a.collapse).
 constexpr int N_PART_ARRAYS = 6;
+__device__ __host__ __forceinline__ int64_t part_at(const CgArgs &a, int k) { return (int64_t)k * a.pstride; }
+__device__ __host__ __forceinline__ int64_t coll_at(const CgArgs &a, int k) { return (int64_t)N_PART_ARRAYS * a.pstride + (int64_t)k * a.prow; }
+__device__ __host__ __forceinline__ int idx_rz(int parity) { return parity; }
+__device__ __host__ __forceinline__ int idx_crit(const CgArgs &a, int parity) { return a.mg ? 4 + parity : parity; }
+constexpr int IDX_PAP = 2, IDX_BREF = 3;
+// where producers write ...
+__device__ __host__ __forceinline__ int64_t part_rz(const CgArgs &a, int parity) { return part_at(a, idx_rz(parity)); }
+__device__ __host__ __forceinline__ int64_t part_pap(const CgArgs &a) { return part_at(a, IDX_PAP); }
+__device__ __host__ __forceinline__ int64_t part_bref(const CgArgs &a) { return part_at(a, IDX_BREF); }
+__device__ __host__ __forceinline__ int64_t part_crit(const CgArgs &a, int parity) { return part_at(a, idx_crit(a, parity)); }
+// ... and where consumers read (a.Gr rows)
+__device__ __host__ __forceinline__ int64_t read_at(const CgArgs &a, int k) { return a.collapse ? coll_at(a, k) : part_at(a, k); }
 constexpr int SC_RZ0 = S::RZ, SC_RZ1 = S::PAP;   // the two parities of the r.z totals
 
 // ------------------------------------------------------------------------------------------
@@ -173,8 +206,8 @@ __global__ __launch_bounds__(CG_NB) void k_cg_apply(Dev d, CgArgs a) {
     bool frozen = false;
     if (FUSE_P) {
         // scalars of this iteration, recomputed identically by every workgroup
-        const double rz_new = column_total<MODAL>(d, d.partials + part_rz(a, a.parity), a.G, l);
-        const double crit = a.mg ? column_total<MODAL>(d, d.partials + part_crit(a, a.parity), a.G, l) : rz_new;
+        const double rz_new = column_total<MODAL>(d, d.partials + read_at(a, idx_rz(a.parity)), a.Gr, l);
+        const double crit = a.mg ? column_total<MODAL>(d, d.partials + read_at(a, idx_crit(a, a.parity)), a.Gr, l) : rz_new;
         const double rz_old = d.scal[(a.parity ? SC_RZ0 : SC_RZ1) + col_of_thread];
         const double bref = d.scal[S::BREF + col_of_thread];
         frozen = (d.flags[col_of_thread] != 0) || (crit <= a.tol2 * bref);
@@ -200,10 +233,10 @@ __global__ __launch_bounds__(CG_NB) void k_cg_apply(Dev d, CgArgs a) {
         const int rp0 = d.rowptr[v0];
         const int cap = a.stage ? a.cap : 0;
         if (a.stage) {
-            for (int i = tid; i <= nrows; i += CG_NB) l.rp[i] = d.rowptr[v0 + i] - rp0;
+            for (int i = tid; i <= nrows; i += a.nb) l.rp[i] = d.rowptr[v0 + i] - rp0;
             __syncthreads();
             const int nloc = min(l.rp[nrows], cap);
-            for (int i = tid; i < nloc; i += CG_NB) {
+            for (int i = tid; i < nloc; i += a.nb) {
                 l.col[i] = d.col[rp0 + i];
                 l.val[i] = d.val[rp0 + i];
             }
@@ -212,7 +245,7 @@ __global__ __launch_bounds__(CG_NB) void k_cg_apply(Dev d, CgArgs a) {
 
         const bool use_p = FUSE_P && (beta != 0.0);
         for (int q = 0; q < a.ept; ++q) {
-            const int e = tid + q * CG_NB;
+            const int e = tid + q * a.nb;
             const int vl = e >> d.tp_shift, t = e & (d.TP - 1);
             if (vl >= nrows || t >= ncols) continue;
             if (FUSE_P && MODAL && frozen) continue;
@@ -277,7 +310,7 @@ __global__ __launch_bounds__(CG_NB) void k_cg_r0(Dev d, CgArgs a, const double *
     double a0 = 0.0, a1 = 0.0;
     if (tile < a.G) {
         for (int q = 0; q < a.ept; ++q) {
-            const int e = threadIdx.x + q * CG_NB;
+            const int e = threadIdx.x + q * a.nb;
             const int v = tile * a.vt + (e >> d.tp_shift), t = e & (d.TP - 1);
             if ((e >> d.tp_shift) >= a.vt || v >= d.V || t >= ncols) continue;
             const int iv = idxV(d, v, t);
@@ -301,7 +334,7 @@ template <bool MODAL>
 __global__ __launch_bounds__(CG_NB) void k_cg_begin(Dev d, CgArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const CgLds l = carve(lds_raw, a.cap);
-    const double bref = column_total<MODAL>(d, d.partials + part_bref(a), a.G, l);
+    const double bref = column_total<MODAL>(d, d.partials + read_at(a, IDX_BREF), a.Gr, l);
     const int tid = threadIdx.x;
     if (tid < a.nc) {
         d.scal[S::BREF + tid] = bref;
@@ -320,7 +353,7 @@ __global__ __launch_bounds__(CG_NB) void k_cg_update(Dev d, CgArgs a) {
     const int tid = threadIdx.x;
     const int col_of_thread = MODAL ? (tid & (d.TP - 1)) : 0;
     const int ncols = n_cols<MODAL>(d);
-    const double pap = column_total<MODAL>(d, d.partials + part_pap(a), a.G, l);
+    const double pap = column_total<MODAL>(d, d.partials + read_at(a, IDX_PAP), a.Gr, l);
     const bool frozen = d.flags[col_of_thread] != 0;
     const bool col_valid = !MODAL || col_of_thread < ncols;
     if (__syncthreads_and((!col_valid || frozen) ? 1 : 0)) return;
@@ -331,7 +364,7 @@ __global__ __launch_bounds__(CG_NB) void k_cg_update(Dev d, CgArgs a) {
     double acc = 0.0;
     if (tile < a.G) {
         for (int q = 0; q < a.ept; ++q) {
-            const int e = tid + q * CG_NB;
+            const int e = tid + q * a.nb;
             const int v = tile * a.vt + (e >> d.tp_shift), t = e & (d.TP - 1);
             if ((e >> d.tp_shift) >= a.vt || v >= d.V || t >= ncols) continue;
             const int iv = idxV(d, v, t);
@@ -395,26 +428,57 @@ __global__ __launch_bounds__(BLOCK) void k_time_modes(Dev d, const double *__res
 // ------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------
-static void cg_tiling(const Dev &d, int *ept_out, int *vt_out, int *G_out) {
-    // elements per thread: smallest power of two that keeps the number of workgroups (= partial sums
-    // every workgroup re-reduces) at or below 1024
-    int ept = 1;
-    while (ept < 8 && ((int64_t)d.V * d.TP + (int64_t)CG_NB * ept - 1) / ((int64_t)CG_NB * ept) > 1024) ept <<= 1;
-    int vt = CG_NB * ept / d.TP;
-    if (vt < 1) vt = 1;
+// Sum the G rows of a partial array into one row (fixed order).  Used for large problems, where every
+// workgroup re-reducing thousands of rows would cost more than one extra tiny kernel.
+// Workgroup b sums the rows g = b, b + gridDim.x, ... and writes row b of dst: launched twice
+// (COLLAPSE_STAGE workgroups, then one) it reduces G rows to one in two short kernels.
+constexpr int COLLAPSE_STAGE = 64;
+__global__ __launch_bounds__(CG_NB) void k_collapse(const double *__restrict__ src, int G, int row, double *__restrict__ dst) {
+    __shared__ double red[CG_NB];
+    const int tid = threadIdx.x;
+    const int c = tid & (row - 1), j = tid / row, J = CG_NB / row;
+    double s = 0.0;
+    for (int g = blockIdx.x + j * gridDim.x; g < G; g += J * gridDim.x) s += src[(int64_t)g * row + c];
+    red[tid] = s;
+    __syncthreads();
+    if (j == 0) {
+        double t = 0.0;
+        for (int k = 0; k < J; ++k) t += red[c + k * row];
+        dst[(int64_t)blockIdx.x * row + c] = t;
+    }
+}
+
+// One element per thread keeps the rows in flight per XCD well inside its L2 (measured: a 7-neighbour
+// gather at V = 100k takes 39 us with 1 element per thread and 56 us with 4, profiles/micro).  Up to 1024
+// workgroups their partial sums are re-reduced inside the consumer kernels; beyond that k_collapse does it.
+static void cg_tiling(const Dev &d, int *nb_out, int *ept_out, int *vt_out, int *G_out, int *collapse_out) {
+    const int ept = 1;
+    int nb = CG_NB;
+    int vt = std::max(1, nb * ept / d.TP);
+    int G = xcd_grid((d.V + vt - 1) / vt);
+    const int collapse = G > 1024 ? 1 : 0;
+    if (collapse) {   // the partial rows are summed by k_collapse anyway: small workgroups, no barriers in the prologue
+        nb = std::max(CG_NB_LARGE, d.TP);
+        vt = std::max(1, nb * ept / d.TP);
+        G = xcd_grid((d.V + vt - 1) / vt);
+    }
+    *nb_out = nb;
     *ept_out = ept;
     *vt_out = vt;
-    *G_out = xcd_grid((d.V + vt - 1) / vt);
+    *G_out = G;
+    *collapse_out = collapse;
 }
 
 static CgArgs make_args(Ctx *c, bool modal) {
     const Dev &d = modal ? c->dcg : c->d;
     CgArgs a{};
-    cg_tiling(d, &a.ept, &a.vt, &a.G);
+    cg_tiling(d, &a.nb, &a.ept, &a.vt, &a.G, &a.collapse);
     a.cap = a.vt * 12 + 64;          // ~7 entries per row on a triangle mesh; entries beyond cap are read from global
     if (a.cap > 3072) a.cap = 3072;  // keep the dynamic LDS below 64 KB
     a.nc = modal ? d.cg_ncol : 1;
-    a.pstride = modal ? a.G * d.TP : a.G;
+    a.prow = modal ? d.TP : 1;
+    a.pstride = a.G * a.prow;
+    a.Gr = a.collapse ? 1 : a.G;
     a.stage = c->cg_stage_lds;
     a.mg = (modal && c->mg.nlev > 1 && c->use_mg) ? 1 : 0;
     a.eps = c->prm.eps;
@@ -423,15 +487,24 @@ static CgArgs make_args(Ctx *c, bool modal) {
 }
 
 int64_t cg_partials_needed(const Dev &d) {
-    int ept, vt, G;
-    cg_tiling(d, &ept, &vt, &G);
-    return N_PART_ARRAYS * (int64_t)d.TP * G;
+    int nb, ept, vt, G, collapse;
+    cg_tiling(d, &nb, &ept, &vt, &G, &collapse);
+    // G rows per array + one collapsed row each + the intermediate rows of the two-stage collapse
+    return N_PART_ARRAYS * (int64_t)d.TP * (G + 1) + (int64_t)COLLAPSE_STAGE * d.TP;
+}
+
+// sum partial array k into its collapsed row (no-op for problems small enough to re-reduce in the consumers)
+static void collapse_if_needed(Ctx *c, const Dev &d, const CgArgs &a, int k) {
+    if (!a.collapse) return;
+    double *stage = d.partials + coll_at(a, N_PART_ARRAYS);   // scratch behind the collapsed rows
+    hipLaunchKernelGGL(k_collapse, dim3(COLLAPSE_STAGE), dim3(CG_NB), 0, c->stream, d.partials + part_at(a, k), a.G, a.prow, stage);
+    hipLaunchKernelGGL(k_collapse, dim3(1), dim3(CG_NB), 0, c->stream, stage, COLLAPSE_STAGE, a.prow, d.partials + coll_at(a, k));
 }
 
 template <bool MODAL>
 static int cg_iterations(Ctx *c, CgArgs a, double *x, int n_iter) {
     const Dev &d = MODAL ? c->dcg : c->d;
-    const size_t lds = cg_lds_bytes(a.cap, a.vt);
+    const size_t lds = cg_lds_bytes(a.cap, a.vt, a.nb);
     for (int it = 0; it < n_iter; ++it) {
         const bool odd = (it & 1) != 0;
         a.parity = odd ? 1 : 0;
@@ -440,11 +513,14 @@ static int cg_iterations(Ctx *c, CgArgs a, double *x, int n_iter) {
         a.p_new = odd ? d.cg_p0 : d.cg_p1;
         a.out = d.cg_Ap;
         a.x = x;
-        hipLaunchKernelGGL((k_cg_apply<MODAL, true>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
-        hipLaunchKernelGGL((k_cg_update<MODAL>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
+        hipLaunchKernelGGL((k_cg_apply<MODAL, true>), dim3(a.G), dim3(a.nb), lds, c->stream, d, a);
+        collapse_if_needed(c, d, a, IDX_PAP);
+        hipLaunchKernelGGL((k_cg_update<MODAL>), dim3(a.G), dim3(a.nb), lds, c->stream, d, a);
+        collapse_if_needed(c, d, a, idx_crit(a, a.parity ^ 1));
         if (a.mg) {
-            int rc = mg_vcycle(c, d.cg_r, d.cg_z, d.cg_Ap, d.partials + part_rz(a, a.parity ^ 1), a.ept, a.vt, a.G);
+            int rc = mg_vcycle(c, d.cg_r, d.cg_z, d.cg_Ap, d.partials + part_rz(a, a.parity ^ 1), a.nb, a.ept, a.vt, a.G);
             if (rc) return rc;
+            collapse_if_needed(c, d, a, idx_rz(a.parity ^ 1));
         }
     }
     DOTS_HIP(hipGetLastError());
@@ -481,16 +557,19 @@ template <bool MODAL>
 static int cg_core(Ctx *c, const double *b, double *x, dots_step_stats *stats) {
     const Dev &d = MODAL ? c->dcg : c->d;
     CgArgs a = make_args(c, MODAL);
-    const size_t lds = cg_lds_bytes(a.cap, a.vt);
+    const size_t lds = cg_lds_bytes(a.cap, a.vt, a.nb);
     a.zin = x;
     a.out = d.cg_Ap;
-    hipLaunchKernelGGL((k_cg_apply<MODAL, false>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
-    hipLaunchKernelGGL((k_cg_r0<MODAL>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a, b, d.cg_Ap);
-    hipLaunchKernelGGL((k_cg_begin<MODAL>), dim3(1), dim3(CG_NB), lds, c->stream, d, a);
+    hipLaunchKernelGGL((k_cg_apply<MODAL, false>), dim3(a.G), dim3(a.nb), lds, c->stream, d, a);
+    hipLaunchKernelGGL((k_cg_r0<MODAL>), dim3(a.G), dim3(a.nb), lds, c->stream, d, a, b, d.cg_Ap);
+    collapse_if_needed(c, d, a, idx_crit(a, 0));
+    collapse_if_needed(c, d, a, IDX_BREF);
+    hipLaunchKernelGGL((k_cg_begin<MODAL>), dim3(1), dim3(a.nb), lds, c->stream, d, a);
     DOTS_HIP(hipGetLastError());
     if (a.mg) {
-        int rc = mg_vcycle(c, d.cg_r, d.cg_z, d.cg_Ap, d.partials + part_rz(a, 0), a.ept, a.vt, a.G);
+        int rc = mg_vcycle(c, d.cg_r, d.cg_z, d.cg_Ap, d.partials + part_rz(a, 0), a.nb, a.ept, a.vt, a.G);
         if (rc) return rc;
+        collapse_if_needed(c, d, a, idx_rz(0));
     }
 
     const int max_iter = c->prm.cg_max_iter > 0 ? c->prm.cg_max_iter : 10000;
@@ -630,7 +709,7 @@ int cg_apply_operator(Ctx *c, const double *x, double *y) {
     CgArgs a = make_args(c, false);
     a.zin = x;
     a.out = y;
-    hipLaunchKernelGGL((k_cg_apply<false, false>), dim3(a.G), dim3(CG_NB), cg_lds_bytes(a.cap, a.vt), c->stream, c->d, a);
+    hipLaunchKernelGGL((k_cg_apply<false, false>), dim3(a.G), dim3(a.nb), cg_lds_bytes(a.cap, a.vt, a.nb), c->stream, c->d, a);
     DOTS_HIP(hipGetLastError());
     return 0;
 }
@@ -641,7 +720,7 @@ int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes) {
     const bool modal = c->lap_solver == DOTS_LAP_MODAL_PCG;
     const Dev &d = modal ? c->dcg : c->d;
     CgArgs a = make_args(c, modal);
-    const size_t lds = cg_lds_bytes(a.cap, a.vt);
+    const size_t lds = cg_lds_bytes(a.cap, a.vt, a.nb);
     if (which == 2 && !a.mg) {
         set_error("bench: no multigrid hierarchy on this context");
         return DOTS_ERR_STATE;
@@ -653,11 +732,11 @@ int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes) {
     const int64_t npart = cg_partials_needed(d);
     std::vector<double> ones((size_t)npart, 0.0);
     for (int k = 0; k < a.nc; ++k) {   // workgroup 0 carries the totals: r.z = crit = 1 (both parities), p.Ap = 2
-        ones[(size_t)(part_rz(a, 0) + k)] = 1.0;
-        ones[(size_t)(part_rz(a, 1) + k)] = 1.0;
-        ones[(size_t)(part_crit(a, 0) + k)] = 1.0;
-        ones[(size_t)(part_crit(a, 1) + k)] = 1.0;
+        for (int64_t base : {part_rz(a, 0), part_rz(a, 1), part_crit(a, 0), part_crit(a, 1), coll_at(a, idx_rz(0)),
+                             coll_at(a, idx_rz(1)), coll_at(a, idx_crit(a, 0)), coll_at(a, idx_crit(a, 1))})
+            ones[(size_t)(base + k)] = 1.0;
         ones[(size_t)(part_pap(a) + k)] = 2.0;
+        ones[(size_t)(coll_at(a, IDX_PAP) + k)] = 2.0;
     }
     std::vector<double> sc(S::TOTAL, 0.0);
     for (int k = 0; k < S::NCMAX; ++k) {
@@ -679,13 +758,13 @@ int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes) {
         a.p_old = (i & 1) ? d.cg_p1 : d.cg_p0;
         a.p_new = (i & 1) ? d.cg_p0 : d.cg_p1;
         if (which == 2) {
-            rc_launch |= mg_vcycle(c, d.cg_r, d.cg_z, d.cg_Ap, d.partials + part_rz(a, 1), a.ept, a.vt, a.G);
+            rc_launch |= mg_vcycle(c, d.cg_r, d.cg_z, d.cg_Ap, d.partials + part_rz(a, 1), a.nb, a.ept, a.vt, a.G);
         } else if (which == 1) {
-            if (modal) hipLaunchKernelGGL((k_cg_update<true>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
-            else hipLaunchKernelGGL((k_cg_update<false>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
+            if (modal) hipLaunchKernelGGL((k_cg_update<true>), dim3(a.G), dim3(a.nb), lds, c->stream, d, a);
+            else hipLaunchKernelGGL((k_cg_update<false>), dim3(a.G), dim3(a.nb), lds, c->stream, d, a);
         } else {
-            if (modal) hipLaunchKernelGGL((k_cg_apply<true, true>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
-            else hipLaunchKernelGGL((k_cg_apply<false, true>), dim3(a.G), dim3(CG_NB), lds, c->stream, d, a);
+            if (modal) hipLaunchKernelGGL((k_cg_apply<true, true>), dim3(a.G), dim3(a.nb), lds, c->stream, d, a);
+            else hipLaunchKernelGGL((k_cg_apply<false, true>), dim3(a.G), dim3(a.nb), lds, c->stream, d, a);
         }
     };
     for (int i = 0; i < 2; ++i) launch(i);

@@ -9,11 +9,12 @@
 // V(1,1) cycle with damped Jacobi (weight w), symmetric as PCG requires, written so that a level
 // costs three kernels and a single neighbour gather pass.  With bt = D^-1 b (delivered by the kernel
 // that produced b) and the product A P precomputed on the host:
-//   down      t   = A bt                                           (the only SpMM on the level's own graph)
-//   restrict  b'  = P^T (b - w t),   bt' = D'^-1 b'                  (pre-smoothing x = w bt folded in: b - A x = b - w t)
-//   post      z   = w bt + P x' + w D^-1 (b - w t - (A P) x')        (x = w bt + P x';  A x = w t + (A P) x')
-// The post kernel reads only its own entries of b, bt, t plus short rows of the (much smaller) coarse
-// vector, so z may overwrite bt in place.  On the finest level post also emits the r.z partial sums
+//   down      r   = b - w A bt                                     (the only SpMM on the level's own graph;
+//                                                                   pre-smoothing x = w bt folded in: r = b - A x)
+//   restrict  b'  = P^T r,   bt' = D'^-1 b'
+//   post      z   = w bt + w D^-1 r + sum_j (P_ij - w D^-1 (A P)_ij) x'_j      (x = w bt + P x';  b - A x = r - (A P) x')
+// P is stored on the pattern of A P, so post is one pass over ~10 entries of the (much smaller) coarse
+// vector and otherwise reads only its own entries of bt and r: z may overwrite bt in place.  On the finest level post also emits the r.z partial sums
 // that the next PCG kernel re-reduces.  The coarsest level is a dense per-mode inverse.  Frozen
 // (converged) modes are skipped everywhere.
 #include "dots_dev.h"
@@ -35,8 +36,9 @@ __device__ __forceinline__ double mg_shift(const Dev &d, const MgArgs &a, int c)
     if (i >= (nrows) || c >= a.ncol) return;                                           \
     if (d.flags[c]) return;
 
-// t = A bt with A = K + s M on the level's pattern (level 0: M is the diagonal mass, vM == nullptr)
-__global__ __launch_bounds__(MG_NB) void k_mg_down(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ bt, double *__restrict__ t) {
+// r = b - w A bt with A = K + s M on the level's pattern (level 0: M is the diagonal mass, vM == nullptr)
+__global__ __launch_bounds__(MG_NB) void k_mg_down(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *__restrict__ bt,
+                                                 double *__restrict__ t) {
     MG_THREAD_SETUP(L.n)
     const double s = mg_shift(d, a, c);
     const int sh = d.tp_shift;
@@ -60,63 +62,51 @@ __global__ __launch_bounds__(MG_NB) void k_mg_down(Dev d, MgLevelDev L, MgArgs a
         for (; j < j1; ++j) sum += L.vK[j] * bt[(L.col[j] << sh) + c];
         sum += s * L.dM[i] * bt[(i << sh) + c];
     }
-    t[(i << sh) + c] = sum;
+    t[(i << sh) + c] = b[(i << sh) + c] - a.omega * sum;
 }
 
-// b' = R (b - w t),  bt' = b' / diag(A')   for the next coarser level (dKc, dMc: its diagonals)
-__global__ __launch_bounds__(MG_NB) void k_mg_restrict(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *__restrict__ t,
-                                                     const double *__restrict__ dKc, const double *__restrict__ dMc, double *__restrict__ bc,
-                                                     double *__restrict__ btc) {
+// b' = R r,  bt' = b' / diag(A')   for the next coarser level (dKc, dMc: its diagonals)
+__global__ __launch_bounds__(MG_NB) void k_mg_restrict(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ r, const double *__restrict__ dKc,
+                                                     const double *__restrict__ dMc, double *__restrict__ bc, double *__restrict__ btc) {
     MG_THREAD_SETUP(L.nc)
     const int sh = d.tp_shift;
-    const double w = a.omega;
     double sum = 0.0;
     int j = L.r_rp[i];
     const int j1 = L.r_rp[i + 1];
     for (; j + 4 <= j1; j += 4) {
-        const int u0 = (L.r_col[j] << sh) + c, u1 = (L.r_col[j + 1] << sh) + c, u2 = (L.r_col[j + 2] << sh) + c,
-                  u3 = (L.r_col[j + 3] << sh) + c;
-        const double b0 = b[u0], b1 = b[u1], b2 = b[u2], b3 = b[u3];
-        const double t0 = t[u0], t1 = t[u1], t2 = t[u2], t3 = t[u3];
-        sum += (L.r_val[j] * (b0 - w * t0) + L.r_val[j + 1] * (b1 - w * t1)) +
-               (L.r_val[j + 2] * (b2 - w * t2) + L.r_val[j + 3] * (b3 - w * t3));
+        const double r0 = r[(L.r_col[j] << sh) + c], r1 = r[(L.r_col[j + 1] << sh) + c], r2 = r[(L.r_col[j + 2] << sh) + c],
+                     r3 = r[(L.r_col[j + 3] << sh) + c];
+        sum += (L.r_val[j] * r0 + L.r_val[j + 1] * r1) + (L.r_val[j + 2] * r2 + L.r_val[j + 3] * r3);
     }
-    for (; j < j1; ++j) {
-        const int u = (L.r_col[j] << sh) + c;
-        sum += L.r_val[j] * (b[u] - w * t[u]);
-    }
+    for (; j < j1; ++j) sum += L.r_val[j] * r[(L.r_col[j] << sh) + c];
     const int ic = (i << sh) + c;
     bc[ic] = sum;
     btc[ic] = sum / (dKc[i] + mg_shift(d, a, c) * dMc[i]);
 }
 
-// P x' and (A P) x' for row i, column c
-__device__ __forceinline__ void mg_coarse_terms(const Dev &d, const MgLevelDev &L, int i, int c, double s, const double *xc, double *corr,
-                                                double *apx) {
+// sum_j (P_ij - w dinv (A P)_ij) x'_j  for row i, column c  (P aligned to the pattern of A P)
+__device__ __forceinline__ double mg_coarse_term(const Dev &d, const MgLevelDev &L, int i, int c, double s, double wdinv, const double *xc) {
     const int sh = d.tp_shift;
-    double p = 0.0, q = 0.0;
-    for (int j = L.p_rp[i]; j < L.p_rp[i + 1]; ++j) p += L.p_val[j] * xc[(L.p_col[j] << sh) + c];
+    double q = 0.0;
     int j = L.ap_rp[i];
     const int j1 = L.ap_rp[i + 1];
     for (; j + 4 <= j1; j += 4) {
         const double x0 = xc[(L.ap_col[j] << sh) + c], x1 = xc[(L.ap_col[j + 1] << sh) + c], x2 = xc[(L.ap_col[j + 2] << sh) + c],
                      x3 = xc[(L.ap_col[j + 3] << sh) + c];
-        q += ((L.ap_vK[j] + s * L.ap_vM[j]) * x0 + (L.ap_vK[j + 1] + s * L.ap_vM[j + 1]) * x1) +
-             ((L.ap_vK[j + 2] + s * L.ap_vM[j + 2]) * x2 + (L.ap_vK[j + 3] + s * L.ap_vM[j + 3]) * x3);
+        q += ((L.ap_vP[j] - wdinv * (L.ap_vK[j] + s * L.ap_vM[j])) * x0 + (L.ap_vP[j + 1] - wdinv * (L.ap_vK[j + 1] + s * L.ap_vM[j + 1])) * x1) +
+             ((L.ap_vP[j + 2] - wdinv * (L.ap_vK[j + 2] + s * L.ap_vM[j + 2])) * x2 + (L.ap_vP[j + 3] - wdinv * (L.ap_vK[j + 3] + s * L.ap_vM[j + 3])) * x3);
     }
-    for (; j < j1; ++j) q += (L.ap_vK[j] + s * L.ap_vM[j]) * xc[(L.ap_col[j] << sh) + c];
-    *corr = p;
-    *apx = q;
+    for (; j < j1; ++j) q += (L.ap_vP[j] - wdinv * (L.ap_vK[j] + s * L.ap_vM[j])) * xc[(L.ap_col[j] << sh) + c];
+    return q;
 }
 
-__global__ __launch_bounds__(MG_NB) void k_mg_post(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *bt,
-                                                 const double *__restrict__ t, const double *__restrict__ xc, double *z) {
+__global__ __launch_bounds__(MG_NB) void k_mg_post(Dev d, MgLevelDev L, MgArgs a, const double *bt, const double *__restrict__ r,
+                                                 const double *__restrict__ xc, double *z) {
     MG_THREAD_SETUP(L.n)
-    const double s = mg_shift(d, a, c), w = a.omega;
-    double corr, apx;
-    mg_coarse_terms(d, L, i, c, s, xc, &corr, &apx);
+    const double s = mg_shift(d, a, c);
+    const double wdinv = a.omega / (L.dK[i] + s * L.dM[i]);
     const int iv = (i << d.tp_shift) + c;
-    z[iv] = w * bt[iv] + corr + w * (b[iv] - w * t[iv] - apx) / (L.dK[i] + s * L.dM[i]);
+    z[iv] = a.omega * bt[iv] + wdinv * r[iv] + mg_coarse_term(d, L, i, c, s, wdinv, xc);
 }
 
 // dense per-mode solve on the coarsest level: x[i][c] = sum_j inv[i][j][c] b[j][c]
@@ -129,39 +119,50 @@ __global__ __launch_bounds__(MG_NB) void k_mg_coarse(Dev d, MgArgs a, int n, con
 }
 
 // Finest-level post-smoothing on the PCG's own tiling (so that the r.z partial sums land where the
-// next k_cg_apply expects them).  z overwrites bt in place.
+// next k_cg_apply expects them).  z overwrites bt in place.  Workgroup size = the PCG's (blockDim.x).
 __global__ __launch_bounds__(1024) void k_mg_post_fine(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *bt,
-                                                       const double *__restrict__ t, const double *__restrict__ xc, double *z,
+                                                       const double *__restrict__ r, const double *__restrict__ xc, double *z,
                                                        double *__restrict__ part, int ept, int vt) {
     __shared__ double red[1024];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NB = blockDim.x;
     const int c = tid & (d.TP - 1);
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     double acc = 0.0;
     const bool live = c < a.ncol && !d.flags[c];
     if (live) {
-        const double s = mg_shift(d, a, c), w = a.omega;
+        const double s = mg_shift(d, a, c);
         for (int q = 0; q < ept; ++q) {
-            const int el = tid + q * 1024;
+            const int el = tid + q * NB;
             const int vl = el >> d.tp_shift;
             const int i = tile * vt + vl;
             if (vl >= vt || i >= L.n) continue;
-            double corr, apx;
-            mg_coarse_terms(d, L, i, c, s, xc, &corr, &apx);
+            const double wdinv = a.omega / (L.dK[i] + s * L.dM[i]);
             const int iv = (i << d.tp_shift) + c;
-            const double bi = b[iv];
-            const double zi = w * bt[iv] + corr + w * (bi - w * t[iv] - apx) / (L.dK[i] + s * L.dM[i]);
+            const double zi = a.omega * bt[iv] + wdinv * r[iv] + mg_coarse_term(d, L, i, c, s, wdinv, xc);
             z[iv] = zi;
-            acc += bi * zi;
+            acc += b[iv] * zi;     // r.z with the PCG residual b (the level-0 right-hand side)
         }
     }
-    red[tid] = acc;
-    __syncthreads();
-    const int j = tid >> d.tp_shift, J = 1024 >> d.tp_shift;
-    if (j == 0 && c < a.ncol) {
-        double tsum = 0.0;
-        for (int k = 0; k < J; ++k) tsum += red[c + (k << d.tp_shift)];
-        part[((int64_t)blockIdx.x << d.tp_shift) + c] = tsum;
+    if (d.TP <= 64) {   // lanes sharing a column are TP apart inside a wave: fold by shuffles, one barrier
+        double sacc = acc;
+        for (int o = 32; o >= d.TP; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+        const int lane = tid & 63, wv = tid >> 6, nw = NB >> 6;
+        if (lane < d.TP) red[wv * d.TP + lane] = sacc;
+        __syncthreads();
+        if (tid < a.ncol) {
+            double tsum = 0.0;
+            for (int k = 0; k < nw; ++k) tsum += red[k * d.TP + tid];
+            part[((int64_t)blockIdx.x << d.tp_shift) + tid] = tsum;
+        }
+    } else {
+        red[tid] = acc;
+        __syncthreads();
+        const int j = tid >> d.tp_shift, J = NB >> d.tp_shift;
+        if (j == 0 && c < a.ncol) {
+            double tsum = 0.0;
+            for (int k = 0; k < J; ++k) tsum += red[c + (k << d.tp_shift)];
+            part[((int64_t)blockIdx.x << d.tp_shift) + c] = tsum;
+        }
     }
 }
 
@@ -169,7 +170,7 @@ static inline int mg_grid(const Dev &d, int rows) { return (int)((((int64_t)rows
 
 // Enqueue one V-cycle.  r: residual; z: holds D^-1 r on entry (written by the PCG update kernel) and the
 // preconditioned residual on exit; r.z partial sums go to `rz_part`.  Level 0 uses `t0` as scratch.
-int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int ept, int vt, int G) {
+int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int nb, int ept, int vt, int G) {
     const Dev &d = c->dcg;   // the PCG's view: its own column range, pitch and sigma
     const MgDev &m = c->mg;
     MgArgs a{c->prm.eps, m.omega, d.cg_ncol};
@@ -181,8 +182,8 @@ int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, i
         const double *b = (l == 0) ? r : L.b;
         const double *bt = (l == 0) ? z : L.bt;
         double *t = (l == 0) ? t0 : L.t;
-        hipLaunchKernelGGL(k_mg_down, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, bt, t);
-        hipLaunchKernelGGL(k_mg_restrict, dim3(mg_grid(d, L.nc)), dim3(MG_NB), 0, c->stream, d, L, a, b, t, C.dK, C.dM, C.b, C.bt);
+        hipLaunchKernelGGL(k_mg_down, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, b, bt, t);
+        hipLaunchKernelGGL(k_mg_restrict, dim3(mg_grid(d, L.nc)), dim3(MG_NB), 0, c->stream, d, L, a, t, C.dK, C.dM, C.b, C.bt);
     }
     // coarsest: the solution lands in its bt slot, which plays the role of z for that level
     {
@@ -194,9 +195,9 @@ int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, i
         const MgLevelDev &L = m.lv[l];
         const double *xc = m.lv[l + 1].bt;
         if (l == 0)
-            hipLaunchKernelGGL(k_mg_post_fine, dim3(G), dim3(1024), 0, c->stream, d, L, a, r, z, t0, xc, z, rz_part, ept, vt);
+            hipLaunchKernelGGL(k_mg_post_fine, dim3(G), dim3(nb), 0, c->stream, d, L, a, r, z, t0, xc, z, rz_part, ept, vt);
         else
-            hipLaunchKernelGGL(k_mg_post, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, L.b, L.bt, L.t, xc, L.bt);
+            hipLaunchKernelGGL(k_mg_post, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, L.bt, L.t, xc, L.bt);
     }
     DOTS_HIP(hipGetLastError());
     return 0;

@@ -259,6 +259,7 @@ class DeviceProblem:
                 h.ap_col = _ptr(arr(L.KP.indices, np.int32), C.c_int32)
                 h.ap_val_k = _ptr(arr(L.KP.data, np.float64), C.c_double)
                 h.ap_val_m = _ptr(arr(L.MP.data, np.float64), C.c_double)
+                h.ap_val_p = _ptr(arr(L.PP.data, np.float64), C.c_double)
         desc = _lib.MgDesc()
         desc.n_levels = len(levels)
         desc.n_cols = int(sigma.size)

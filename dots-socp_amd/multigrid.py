@@ -27,6 +27,7 @@ class MgLevel:
     R: sp.csr_matrix | None     # restriction = P^T (n_coarse x n)
     KP: sp.csr_matrix | None = None   # K @ P  (n x n_coarse), used by the fused post-smoothing kernel
     MP: sp.csr_matrix | None = None   # M @ P on the pattern of KP
+    PP: sp.csr_matrix | None = None   # P itself on the pattern of KP (zeros where P has no entry)
     dK: np.ndarray = field(default=None)   # diag(K)
     dM: np.ndarray = field(default=None)   # diag(M)
     cand: np.ndarray = field(default=None)  # near-null-space candidate of K on this level (K @ cand = 0)
@@ -142,9 +143,10 @@ def build_hierarchy(K: sp.csr_matrix, mass: np.ndarray, max_levels: int = 8, coa
         level.P = P
         level.R = P.T.tocsr()
         level.R.sort_indices()
-        pat_ap = _pattern_union(abs(K) @ abs(P), abs(Mp) @ abs(P))
+        pat_ap = _pattern_union(abs(K) @ abs(P), abs(Mp) @ abs(P), abs(P))
         level.KP = _align_to_pattern(pat_ap, (K @ P).tocsr())
         level.MP = _align_to_pattern(pat_ap, (Mp @ P).tocsr())
+        level.PP = _align_to_pattern(pat_ap, P)
         K = (level.R @ K @ P).tocsr()
         M = (level.R @ Mp @ P).tocsr()
         K.sort_indices()

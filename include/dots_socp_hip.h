@@ -239,6 +239,7 @@ typedef struct dots_mg_level {
     const int32_t *ap_col;
     const double *ap_val_k;
     const double *ap_val_m;
+    const double *ap_val_p;    /* P itself on the pattern of A P (zero where P has no entry) */
 } dots_mg_level;
 
 typedef struct dots_mg_desc {

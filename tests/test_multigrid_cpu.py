@@ -40,6 +40,7 @@ def test_hierarchy_invariants(name, kw):
             assert np.array_equal(lv.KP.indptr, lv.MP.indptr) and np.array_equal(lv.KP.indices, lv.MP.indices)
             assert abs(lv.KP - lv.K @ lv.P).max() < 1e-12 * abs(lv.KP).max()
             assert abs(lv.MP - lv.M @ lv.P).max() < 1e-12 * max(abs(lv.MP).max(), 1e-300)
+            assert np.array_equal(lv.PP.indices, lv.KP.indices) and abs(lv.PP - lv.P).max() == 0.0
             Kl, M = (lv.R @ lv.K @ lv.P).tocsr(), (lv.R @ lv.M @ lv.P).tocsr()
     # the near-null-space candidate is carried exactly: K_l c_l = 0 and P_l c_{l+1} = c_l
     assert np.allclose(levels[0].cand, 1.0)
