@@ -211,7 +211,7 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     for (int v = 0; v < V; ++v) nb += (p->mu0[v] * p->mu0[v] + p->mu1[v] * p->mu1[v]) / p->mass_vert[v];
     q.norm_boundary = std::sqrt(nb / (d.T + 1));      // = r h sqrt(norm_square_center(boundary / mass)), :296
     q.congestion = 0.0; q.tau = 1.9; q.eps = 0.0; q.prim_scale = 1.0; q.dual_scale = 1.0; q.boundary_scale = 1.0;
-    q.cg_tol = 1e-10; q.cg_max_iter = 20000;
+    q.cg_tol = 1e-8; q.cg_max_iter = 20000;
     DOTS_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -340,6 +340,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
     dots_ctx *c = new dots_ctx();
     c->device = desc->device;
     if (const char *e = getenv("DOTS_CG_STAGE_LDS")) c->cg_stage_lds = atoi(e) != 0;
+    if (const char *e = getenv("DOTS_MG_TAIL_ROWS")) c->mg_tail_rows = atoi(e);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);

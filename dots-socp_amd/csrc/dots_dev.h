@@ -152,6 +152,7 @@ struct Ctx {
     int cg_stage_lds = 1;         // stage CSR row blocks in LDS (DOTS_CG_STAGE_LDS=0 disables, for A/B measurements)
     MgDev mg{};                   // multigrid preconditioner (nlev == 0: Jacobi only)
     int use_mg = 1;
+    int mg_tail_rows = 256;       // levels with at most this many rows run inside the single tail launch (DOTS_MG_TAIL_ROWS)
     int cg_graph_mg = -1;
     void *mg_allocs[160]{};
     int n_mg_allocs = 0;

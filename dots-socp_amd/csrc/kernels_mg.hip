@@ -14,14 +14,23 @@
 //   restrict  b'  = P^T r,   bt' = D'^-1 b'
 //   post      z   = w bt + w D^-1 r + sum_j (P_ij - w D^-1 (A P)_ij) x'_j      (x = w bt + P x';  b - A x = r - (A P) x')
 // P is stored on the pattern of A P, so post is one pass over ~10 entries of the (much smaller) coarse
-// vector and otherwise reads only its own entries of bt and r: z may overwrite bt in place.  On the finest level post also emits the r.z partial sums
-// that the next PCG kernel re-reduces.  The coarsest level is a dense per-mode inverse.  Frozen
-// (converged) modes are skipped everywhere.
+// vector and otherwise reads only its own entries of bt and r: z may overwrite bt in place.
+// On the finest level post also emits the r.z partial sums that the next PCG kernel re-reduces.
+//
+// The coarse tail.  The smallest levels (at most Ctx::mg_tail_rows rows, default 256) are pure launch
+// latency.  The time-mode columns are independent of each other, so ONE kernel (k_mg_tail) walks those
+// levels -- down, restrict, ..., dense coarsest solve, ..., post -- with one workgroup per column and
+// workgroup barriers between the phases.  Measured on MI355X (us per V-cycle, sphere10k / torus100k):
+// tail of <= 64 rows 71.2 / 207.8, <= 256 rows 67.0 / 206.4, <= 2048 rows 93.7 / 286.0: a single
+// workgroup per column starves once a level has more than a few hundred rows, so only the last two
+// levels go into the tail.
+// Frozen (converged) modes are skipped everywhere.
 #include "dots_dev.h"
 
 namespace dots {
 
 constexpr int MG_NB = 256;
+constexpr int MG_TAIL_NB = 1024;
 
 struct MgArgs {
     double eps, omega;
@@ -30,16 +39,10 @@ struct MgArgs {
 
 __device__ __forceinline__ double mg_shift(const Dev &d, const MgArgs &a, int c) { return d.sigma[c] + a.eps; }
 
-#define MG_THREAD_SETUP(nrows)                                                        \
-    const int64_t e = (int64_t)blockIdx.x * MG_NB + threadIdx.x;                       \
-    const int i = (int)(e >> d.tp_shift), c = (int)(e & (d.TP - 1));                   \
-    if (i >= (nrows) || c >= a.ncol) return;                                           \
-    if (d.flags[c]) return;
-
-// r = b - w A bt with A = K + s M on the level's pattern (level 0: M is the diagonal mass, vM == nullptr)
-__global__ __launch_bounds__(MG_NB) void k_mg_down(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *__restrict__ bt,
-                                                 double *__restrict__ t) {
-    MG_THREAD_SETUP(L.n)
+// ---- per-element work of the three level kernels -----------------------------------------------
+// r_i = b_i - w (A bt)_i  with A = K + s M on the level's pattern (level 0: M is the diagonal mass, vM == nullptr)
+__device__ __forceinline__ void mg_down_elem(const Dev &d, const MgLevelDev &L, const MgArgs &a, const double *b, const double *bt, double *r,
+                                             int i, int c) {
     const double s = mg_shift(d, a, c);
     const int sh = d.tp_shift;
     double sum = 0.0;
@@ -62,13 +65,12 @@ __global__ __launch_bounds__(MG_NB) void k_mg_down(Dev d, MgLevelDev L, MgArgs a
         for (; j < j1; ++j) sum += L.vK[j] * bt[(L.col[j] << sh) + c];
         sum += s * L.dM[i] * bt[(i << sh) + c];
     }
-    t[(i << sh) + c] = b[(i << sh) + c] - a.omega * sum;
+    r[(i << sh) + c] = b[(i << sh) + c] - a.omega * sum;
 }
 
-// b' = R r,  bt' = b' / diag(A')   for the next coarser level (dKc, dMc: its diagonals)
-__global__ __launch_bounds__(MG_NB) void k_mg_restrict(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ r, const double *__restrict__ dKc,
-                                                     const double *__restrict__ dMc, double *__restrict__ bc, double *__restrict__ btc) {
-    MG_THREAD_SETUP(L.nc)
+// b'_i = (R r)_i,  bt'_i = b'_i / diag(A')_i   for the next coarser level (dKc, dMc: its diagonals)
+__device__ __forceinline__ void mg_restrict_elem(const Dev &d, const MgLevelDev &L, const MgArgs &a, const double *r, const double *dKc,
+                                                 const double *dMc, double *bc, double *btc, int i, int c) {
     const int sh = d.tp_shift;
     double sum = 0.0;
     int j = L.r_rp[i];
@@ -84,9 +86,12 @@ __global__ __launch_bounds__(MG_NB) void k_mg_restrict(Dev d, MgLevelDev L, MgAr
     btc[ic] = sum / (dKc[i] + mg_shift(d, a, c) * dMc[i]);
 }
 
-// sum_j (P_ij - w dinv (A P)_ij) x'_j  for row i, column c  (P aligned to the pattern of A P)
-__device__ __forceinline__ double mg_coarse_term(const Dev &d, const MgLevelDev &L, int i, int c, double s, double wdinv, const double *xc) {
+// z_i = w bt_i + w dinv r_i + sum_j (P_ij - w dinv (A P)_ij) x'_j      (P aligned to the pattern of A P)
+__device__ __forceinline__ double mg_post_value(const Dev &d, const MgLevelDev &L, const MgArgs &a, const double *bt, const double *r,
+                                                const double *xc, int i, int c) {
     const int sh = d.tp_shift;
+    const double s = mg_shift(d, a, c);
+    const double wdinv = a.omega / (L.dK[i] + s * L.dM[i]);
     double q = 0.0;
     int j = L.ap_rp[i];
     const int j1 = L.ap_rp[i + 1];
@@ -97,25 +102,74 @@ __device__ __forceinline__ double mg_coarse_term(const Dev &d, const MgLevelDev 
              ((L.ap_vP[j + 2] - wdinv * (L.ap_vK[j + 2] + s * L.ap_vM[j + 2])) * x2 + (L.ap_vP[j + 3] - wdinv * (L.ap_vK[j + 3] + s * L.ap_vM[j + 3])) * x3);
     }
     for (; j < j1; ++j) q += (L.ap_vP[j] - wdinv * (L.ap_vK[j] + s * L.ap_vM[j])) * xc[(L.ap_col[j] << sh) + c];
-    return q;
+    const int iv = (i << sh) + c;
+    return a.omega * bt[iv] + wdinv * r[iv] + q;
+}
+
+// ---- one kernel per phase (levels above the tail) --------------------------------------------------
+#define MG_THREAD_SETUP(nrows)                                                        \
+    const int64_t e = (int64_t)blockIdx.x * MG_NB + threadIdx.x;                       \
+    const int i = (int)(e >> d.tp_shift), c = (int)(e & (d.TP - 1));                   \
+    if (i >= (nrows) || c >= a.ncol) return;                                           \
+    if (d.flags[c]) return;
+
+__global__ __launch_bounds__(MG_NB) void k_mg_down(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ b, const double *__restrict__ bt,
+                                                 double *__restrict__ r) {
+    MG_THREAD_SETUP(L.n)
+    mg_down_elem(d, L, a, b, bt, r, i, c);
+}
+
+__global__ __launch_bounds__(MG_NB) void k_mg_restrict(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ r, const double *__restrict__ dKc,
+                                                     const double *__restrict__ dMc, double *__restrict__ bc, double *__restrict__ btc) {
+    MG_THREAD_SETUP(L.nc)
+    mg_restrict_elem(d, L, a, r, dKc, dMc, bc, btc, i, c);
 }
 
 __global__ __launch_bounds__(MG_NB) void k_mg_post(Dev d, MgLevelDev L, MgArgs a, const double *bt, const double *__restrict__ r,
                                                  const double *__restrict__ xc, double *z) {
     MG_THREAD_SETUP(L.n)
-    const double s = mg_shift(d, a, c);
-    const double wdinv = a.omega / (L.dK[i] + s * L.dM[i]);
-    const int iv = (i << d.tp_shift) + c;
-    z[iv] = a.omega * bt[iv] + wdinv * r[iv] + mg_coarse_term(d, L, i, c, s, wdinv, xc);
+    z[(i << d.tp_shift) + c] = mg_post_value(d, L, a, bt, r, xc, i, c);
 }
 
-// dense per-mode solve on the coarsest level: x[i][c] = sum_j inv[i][j][c] b[j][c]
-__global__ __launch_bounds__(MG_NB) void k_mg_coarse(Dev d, MgArgs a, int n, const double *__restrict__ inv, const double *__restrict__ b,
-                                                   double *__restrict__ x) {
-    MG_THREAD_SETUP(n)
-    double sum = 0.0;
-    for (int j = 0; j < n; ++j) sum += inv[(((int64_t)i * n + j) << d.tp_shift) + c] * b[(j << d.tp_shift) + c];
-    x[(i << d.tp_shift) + c] = sum;
+// ---- the coarse tail in one launch: one workgroup per time-mode column ------------------------------
+struct MgTail {
+    int first, nlev;            // levels [first, nlev) of the hierarchy
+    MgLevelDev lv[8];           // lv[k] = level first + k
+    const double *coarse_inv;   // [nL][nL][TP]
+};
+
+__global__ __launch_bounds__(MG_TAIL_NB) void k_mg_tail(Dev d, MgTail T, MgArgs a) {
+    const int c = blockIdx.x;
+    if (c >= a.ncol || d.flags[c]) return;
+    const int tid = threadIdx.x, sh = d.tp_shift;
+    const int nk = T.nlev - T.first;
+    for (int k = 0; k + 1 < nk; ++k) {
+        const MgLevelDev &L = T.lv[k];
+        const MgLevelDev &C = T.lv[k + 1];
+        for (int i = tid; i < L.n; i += MG_TAIL_NB) mg_down_elem(d, L, a, L.b, L.bt, L.t, i, c);
+        __syncthreads();
+        for (int i = tid; i < L.nc; i += MG_TAIL_NB) mg_restrict_elem(d, L, a, L.t, C.dK, C.dM, C.b, C.bt, i, c);
+        __syncthreads();
+    }
+    {   // dense per-mode solve on the coarsest level; the solution lands in its bt slot
+        const MgLevelDev &L = T.lv[nk - 1];
+        const int n = L.n;
+        for (int i = tid; i < n; i += MG_TAIL_NB) {
+            double sum = 0.0;
+            for (int j = 0; j < n; ++j) sum += T.coarse_inv[(((int64_t)i * n + j) << sh) + c] * L.b[(j << sh) + c];
+            L.bt[(i << sh) + c] = sum;
+        }
+        __syncthreads();
+    }
+    for (int k = nk - 2; k >= 0; --k) {
+        const MgLevelDev &L = T.lv[k];
+        const double *xc = T.lv[k + 1].bt;
+        for (int i = tid; i < L.n; i += MG_TAIL_NB) {
+            const double z = mg_post_value(d, L, a, L.bt, L.t, xc, i, c);
+            L.bt[(i << sh) + c] = z;     // own entry only: in place is safe
+        }
+        __syncthreads();
+    }
 }
 
 // Finest-level post-smoothing on the PCG's own tiling (so that the r.z partial sums land where the
@@ -130,15 +184,13 @@ __global__ __launch_bounds__(1024) void k_mg_post_fine(Dev d, MgLevelDev L, MgAr
     double acc = 0.0;
     const bool live = c < a.ncol && !d.flags[c];
     if (live) {
-        const double s = mg_shift(d, a, c);
         for (int q = 0; q < ept; ++q) {
             const int el = tid + q * NB;
             const int vl = el >> d.tp_shift;
             const int i = tile * vt + vl;
             if (vl >= vt || i >= L.n) continue;
-            const double wdinv = a.omega / (L.dK[i] + s * L.dM[i]);
             const int iv = (i << d.tp_shift) + c;
-            const double zi = a.omega * bt[iv] + wdinv * r[iv] + mg_coarse_term(d, L, i, c, s, wdinv, xc);
+            const double zi = mg_post_value(d, L, a, bt, r, xc, i, c);
             z[iv] = zi;
             acc += b[iv] * zi;     // r.z with the PCG residual b (the level-0 right-hand side)
         }
@@ -175,8 +227,12 @@ int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, i
     const MgDev &m = c->mg;
     MgArgs a{c->prm.eps, m.omega, d.cg_ncol};
     const int nl = m.nlev;
-    // down sweep
-    for (int l = 0; l + 1 < nl; ++l) {
+    // first level of the tail: the first level >= 1 with few enough rows (always at least the coarsest)
+    int first_tail = nl - 1;
+    for (int l = 1; l < nl; ++l)
+        if (m.lv[l].n <= c->mg_tail_rows && nl - l <= 8) { first_tail = l; break; }
+    // down sweep above the tail
+    for (int l = 0; l < first_tail; ++l) {
         const MgLevelDev &L = m.lv[l];
         const MgLevelDev &C = m.lv[l + 1];
         const double *b = (l == 0) ? r : L.b;
@@ -185,13 +241,17 @@ int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, i
         hipLaunchKernelGGL(k_mg_down, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, b, bt, t);
         hipLaunchKernelGGL(k_mg_restrict, dim3(mg_grid(d, L.nc)), dim3(MG_NB), 0, c->stream, d, L, a, t, C.dK, C.dM, C.b, C.bt);
     }
-    // coarsest: the solution lands in its bt slot, which plays the role of z for that level
+    // the tail (at least the dense coarsest solve): one workgroup per column
     {
-        const MgLevelDev &L = m.lv[nl - 1];
-        hipLaunchKernelGGL(k_mg_coarse, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, a, L.n, m.coarse_inv, L.b, L.bt);
+        MgTail T{};
+        T.first = first_tail;
+        T.nlev = nl;
+        for (int l = first_tail; l < nl; ++l) T.lv[l - first_tail] = m.lv[l];
+        T.coarse_inv = m.coarse_inv;
+        hipLaunchKernelGGL(k_mg_tail, dim3(d.cg_ncol), dim3(MG_TAIL_NB), 0, c->stream, d, T, a);
     }
-    // up sweep: level l's result is written over its bt
-    for (int l = nl - 2; l >= 0; --l) {
+    // up sweep above the tail: level l's result is written over its bt
+    for (int l = first_tail - 1; l >= 0; --l) {
         const MgLevelDev &L = m.lv[l];
         const double *xc = m.lv[l + 1].bt;
         if (l == 0)
