@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--lap-solver", default="modal_pcg", choices=["modal_pcg", "spacetime_pcg"])
     ap.add_argument("--preconditioner", default="multigrid", choices=["multigrid", "jacobi"])
     ap.add_argument("--cg-tol", type=float, default=None)
+    ap.add_argument("--mg-coarsest", type=int, default=None, help="rows of the dense coarsest multigrid level (default: solver default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-tol", action="store_true")
     ap.add_argument("--no-reorder", action="store_true", help="keep the generator's vertex numbering (A/B of the RCM renumbering)")
@@ -118,6 +119,7 @@ def main():
     geom, _scale = meshes.example(wl["example"], **wl["kw"])
     n_time, congestion, tol = wl["n_time"], wl["congestion"], wl["tol"]
     cg_tol = args.cg_tol if args.cg_tol is not None else DEFAULT_CG_TOL
+    mg_kw = {} if args.mg_coarsest is None else {"mg_coarsest": args.mg_coarsest}
     V, F = geom["vertices"].shape[0], geom["triangles"].shape[0]
 
     dist = None
@@ -133,11 +135,11 @@ def main():
 
         alm = ShardedAlmSolver(n_time, geom, comm=TorchComm(), congestion=congestion, nit=args.warmup + args.steps + 8,
                                tol=1e-30, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner,
-                               time_limit=float("inf"), reorder=not args.no_reorder)
+                               time_limit=float("inf"), reorder=not args.no_reorder, **mg_kw)
     else:
         alm = AlmSolver(n_time, geom, congestion=congestion, nit=args.warmup + args.steps + 8, tol=1e-30,
                         lap_solver=args.lap_solver, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner,
-                        time_limit=float("inf"), reorder=not args.no_reorder)
+                        time_limit=float("inf"), reorder=not args.no_reorder, **mg_kw)
 
     def barrier():
         alm.dev.sync()
@@ -188,7 +190,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_time_to_tol:
         t1 = time.perf_counter()
         solver = AlmSolver(n_time, geom, congestion=congestion, nit=20000, tol=tol, lap_solver=args.lap_solver, cg_tol=cg_tol,
-                           device=local_rank, preconditioner=args.preconditioner, reorder=not args.no_reorder)
+                           device=local_rank, preconditioner=args.preconditioner, reorder=not args.no_reorder, **mg_kw)
         setup_s = time.perf_counter() - t1
         t1 = time.perf_counter()
         while not solver.iterate():

@@ -131,6 +131,25 @@ __global__ __launch_bounds__(MG_NB) void k_mg_post(Dev d, MgLevelDev L, MgArgs a
     z[(i << d.tp_shift) + c] = mg_post_value(d, L, a, bt, r, xc, i, c);
 }
 
+// dense per-mode solve on the coarsest level, one thread per (row, column): x[i][c] = sum_j inv[i][j][c] b[j][c]
+// (loads coalesce over the column index; used when the coarsest level is too large for the tail kernel)
+__global__ __launch_bounds__(MG_NB) void k_mg_coarse(Dev d, MgArgs a, int n, const double *__restrict__ inv, const double *__restrict__ b,
+                                                   double *__restrict__ x) {
+    MG_THREAD_SETUP(n)
+    const int sh = d.tp_shift;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const double *row = inv + (((int64_t)i * n) << sh) + c;
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+        s0 += row[(int64_t)j << sh] * b[(j << sh) + c];
+        s1 += row[(int64_t)(j + 1) << sh] * b[((j + 1) << sh) + c];
+        s2 += row[(int64_t)(j + 2) << sh] * b[((j + 2) << sh) + c];
+        s3 += row[(int64_t)(j + 3) << sh] * b[((j + 3) << sh) + c];
+    }
+    for (; j < n; ++j) s0 += row[(int64_t)j << sh] * b[(j << sh) + c];
+    x[(i << sh) + c] = (s0 + s1) + (s2 + s3);
+}
+
 // ---- the coarse tail in one launch: one workgroup per time-mode column ------------------------------
 struct MgTail {
     int first, nlev;            // levels [first, nlev) of the hierarchy
@@ -241,8 +260,12 @@ int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, i
         hipLaunchKernelGGL(k_mg_down, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, b, bt, t);
         hipLaunchKernelGGL(k_mg_restrict, dim3(mg_grid(d, L.nc)), dim3(MG_NB), 0, c->stream, d, L, a, t, C.dK, C.dM, C.b, C.bt);
     }
-    // the tail (at least the dense coarsest solve): one workgroup per column
-    {
+    // the tail (at least the dense coarsest solve): one workgroup per column; a large coarsest level on
+    // its own is solved by the flat kernel instead (one thread per entry, coalesced over the columns)
+    if (first_tail == nl - 1 && m.lv[nl - 1].n > 64) {
+        const MgLevelDev &L = m.lv[nl - 1];
+        hipLaunchKernelGGL(k_mg_coarse, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, a, L.n, m.coarse_inv, L.b, L.bt);
+    } else {
         MgTail T{};
         T.first = first_tail;
         T.nlev = nl;

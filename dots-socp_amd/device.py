@@ -201,7 +201,7 @@ class DeviceProblem:
         return out
 
     # ---- multigrid preconditioner of the modal PCG
-    def setup_multigrid(self, eps=0.0, omega=2.0 / 3.0, coarsest=96, mode_slice=None):
+    def setup_multigrid(self, eps=0.0, omega=2.0 / 3.0, coarsest=256, mode_slice=None):
         """Build the smoothed-aggregation hierarchy on the host and upload it (see multigrid.py).
 
         ``mode_slice``: the time modes this context solves (default: all T+1).  Returns the

@@ -63,7 +63,7 @@ class AlmSolver:
     def __init__(self, n_time, geometry, congestion=0.0, nit=1000, eps=0.0, tol=1e-4, tau=1.90, is_z_scaling=True,
                  is_constant_scaling=False, check_kkt_step_by_step=False, init_solution=None, tol_checkpoints=None,
                  time_limit=1000, lap_solver="modal_pcg", cg_tol=DEFAULT_CG_TOL, cg_max_iter=20000, device=0, reorder=True,
-                 preconditioner="multigrid", mg_coarsest=96, mode_shard=None):
+                 preconditioner="multigrid", mg_coarsest=256, mode_shard=None):
         self.tol_checkpoints = _validate_checkpoints(tol_checkpoints, tol)
         self.checkpoint_solutions = []
         self.n_time, self.nit, self.tol, self.time_limit = int(n_time), int(nit), tol, time_limit
@@ -343,7 +343,7 @@ def solver_socp(
         device=0,
         reorder=True,
         preconditioner="multigrid",
-        mg_coarsest=96,
+        mg_coarsest=256,
 ):
     """SOCP for dynamical optimal transport on a discrete surface, on the GPU.
 
