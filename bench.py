@@ -8,8 +8,8 @@ One "step" is one full pass of the solver's main loop (reference solver_socp.py:
 whatever KKT evaluation / penalty update the lazy schedule puts on that iteration.  All state is
 resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line.
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the T+1 time nodes are sharded in
-slabs; see dots-socp_amd/distributed.py.  `value` is whole-job iterations/s (the iterations are
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the Laplacian solve is sharded over the
+T+1 time modes with one all-gather per iteration; see dots-socp_amd/distributed.py.  `value` is whole-job iterations/s (the iterations are
 collective: every rank advances the same ALM iteration).
 """
 from __future__ import annotations
