@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="sphere10k", choices=sorted(WORKLOADS))
-    ap.add_argument("--lap-solver", default="modal_pcg", choices=["modal_pcg", "spacetime_pcg"])
+    ap.add_argument("--lap-solver", default="modal_pcg", choices=["modal_direct", "modal_pcg", "spacetime_pcg"])
     ap.add_argument("--preconditioner", default="multigrid", choices=["multigrid", "jacobi"])
     ap.add_argument("--cg-tol", type=float, default=None)
     ap.add_argument("--mg-coarsest", type=int, default=None, help="rows of the dense coarsest multigrid level (default: solver default)")
@@ -163,20 +163,32 @@ def main():
     cg_per_it = (alm.cg_total - cg0) / max(args.steps, 1)
     steps_time = dict(alm.run_history.steps_time)
 
-    # ---- roofline of the dominant kernel (PCG operator application), measured with hipEvents on the
-    # context's own stream in the state the timed region left behind
-    ms_apply, bytes_apply = alm.dev.bench_kernel(which=0, reps=200)
-    ms_update, bytes_update = alm.dev.bench_kernel(which=1, reps=200)
-    achieved = bytes_apply / (ms_apply * 1e-3) / 1e9
-    roofline = {
-        "bound": "hbm", "kernel": "k_cg_apply (fused direction update + K p + p.Kp partials)",
-        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,
-        "ms_per_launch": ms_apply, "algorithmic_bytes_per_launch": bytes_apply,
-        "second_kernel": {"kernel": "k_cg_update", "ms_per_launch": ms_update,
-                          "achieved": bytes_update / (ms_update * 1e-3) / 1e9, "algorithmic_bytes_per_launch": bytes_update},
-        "working_set_note": "CG working set fits the 256 MiB Infinity Cache at this size" if V * (n_time + 1) * 8 * 6 < 256e6 else "",
-    }
+    # ---- roofline of the dominant kernel(s), measured with hipEvents on the context's own stream in the
+    # state the timed region left behind
+    if getattr(alm, "front_summary", None):
+        fs = alm.front_summary
+        ms_solve, bytes_solve = alm.dev.bench_kernel(which=3, reps=100)
+        achieved = bytes_solve / (ms_solve * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "k_front_fwd + k_front_bwd (the two triangular sweeps of the multifrontal factor: "
+                                      f"{2 * fs['levels']} launches per solve, one per tree height and sweep)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "ms_per_solve": ms_solve, "launches_per_solve": 2 * fs["levels"], "ms_per_launch": ms_solve / (2 * fs["levels"]),
+            "algorithmic_bytes_per_solve": bytes_solve, "factor": fs,
+        }
+    else:
+        ms_apply, bytes_apply = alm.dev.bench_kernel(which=0, reps=200)
+        ms_update, bytes_update = alm.dev.bench_kernel(which=1, reps=200)
+        achieved = bytes_apply / (ms_apply * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "k_cg_apply (fused direction update + K p + p.Kp partials)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "ms_per_launch": ms_apply, "algorithmic_bytes_per_launch": bytes_apply,
+            "second_kernel": {"kernel": "k_cg_update", "ms_per_launch": ms_update,
+                              "achieved": bytes_update / (ms_update * 1e-3) / 1e9, "algorithmic_bytes_per_launch": bytes_update},
+            "working_set_note": "CG working set fits the 256 MiB Infinity Cache at this size" if V * (n_time + 1) * 8 * 6 < 256e6 else "",
+        }
     if getattr(alm, "mg_summary", None):
         ms_vc, bytes_vc = alm.dev.bench_kernel(which=2, reps=100)
         roofline["multigrid_vcycle"] = {

@@ -27,7 +27,7 @@ EXPORTS = [
     "dots_sync", "dots_upload", "dots_download", "dots_array_count", "dots_step", "dots_run_phase", "dots_kkt",
     "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
-    "dots_step_begin", "dots_step_end", "dots_shard_elems",
+    "dots_step_begin", "dots_step_end", "dots_shard_elems", "dots_front_setup", "dots_front_enable", "dots_front_pitch",
 ]
 
 
@@ -74,6 +74,16 @@ class MgDesc(C.Structure):
     _fields_ = [
         ("n_levels", C.c_int32), ("n_cols", C.c_int32), ("omega", C.c_double),
         ("levels", C.POINTER(MgLevel)), ("coarse_inverse", _f64p),
+    ]
+
+
+class FrontDesc(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("n_levels", C.c_int32), ("n_modes", C.c_int32), ("pitch", C.c_int32),
+        ("n_front_rows", C.c_int64), ("n_entries", C.c_int64), ("update_rows", C.c_int64),
+        ("node_n", _i32p), ("node_b", _i32p), ("node_foff", C.POINTER(C.c_int64)), ("node_ioff", C.POINTER(C.c_int64)),
+        ("node_uoff", C.POINTER(C.c_int64)), ("node_child", _i32p), ("front_idx", _i32p), ("pull0", _i32p), ("pull1", _i32p),
+        ("level_ptr", _i32p), ("level_nodes", _i32p), ("values", _f64p),
     ]
 
 
@@ -141,6 +151,9 @@ def load():
     lib.dots_shard_elems.restype = C.c_int64
     lib.dots_mg_setup.argtypes = [vp, C.POINTER(MgDesc)]
     lib.dots_mg_enable.argtypes = [vp, C.c_int]
+    lib.dots_front_setup.argtypes = [vp, C.POINTER(FrontDesc)]
+    lib.dots_front_enable.argtypes = [vp, C.c_int]
+    lib.dots_front_pitch.argtypes = [vp]
     lib.dots_device_bytes.argtypes = [vp]
     lib.dots_device_bytes.restype = C.c_int64
     for n in EXPORTS:

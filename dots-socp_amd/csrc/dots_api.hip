@@ -356,6 +356,7 @@ int dots_destroy(dots_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->cg_graph) (void)hipGraphExecDestroy(c->cg_graph);
     for (int i = 0; i < c->n_mg_allocs; ++i) (void)hipFree(c->mg_allocs[i]);
+    for (int i = 0; i < c->n_front_allocs; ++i) (void)hipFree(c->front_allocs[i]);
     for (int i = 0; i < c->n_allocs; ++i) (void)hipFree(c->allocs[i]);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
@@ -643,6 +644,26 @@ int dots_mg_enable(dots_ctx *c, int on) {
     if (rc) return rc;
     c->use_mg = on ? 1 : 0;
     return 0;
+}
+
+int dots_front_setup(dots_ctx *c, const dots_front_desc *desc) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (c->lap_solver != DOTS_LAP_MODAL_PCG) { set_error("the direct solve needs the modal solver"); return DOTS_ERR_ARGUMENT; }
+    return front_setup(c, desc);
+}
+
+int dots_front_enable(dots_ctx *c, int on) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (on && c->front.n_nodes == 0) { set_error("front_enable: no factor installed"); return DOTS_ERR_STATE; }
+    c->use_front = on ? 1 : 0;
+    return 0;
+}
+
+int dots_front_pitch(dots_ctx *c) {
+    if (check(c)) return -1;
+    return c->dcg.TP;
 }
 
 int dots_bench_kernel(dots_ctx *c, int which, int reps, double *ms, double *bytes) {

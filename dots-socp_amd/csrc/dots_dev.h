@@ -89,6 +89,19 @@ struct MgDev {
     double omega = 2.0 / 3.0;
 };
 
+// Direct (multifrontal) solve of the modal problems: the factor of dots-socp_amd/frontal.py on the device.
+// F_p = [L_pp^-1 ; A_bs A_ss^-1] of node p starts at F + (foff[p] << tp_shift), entry (i, j, mode) at
+// ((i * n_p + j) << tp_shift) + mode: the mode index is fastest, as in every node array.
+struct FrontDev {
+    int n_nodes = 0, n_levels = 0;
+    const int *node_n = nullptr, *node_b = nullptr, *child = nullptr;       // child: [n_nodes][2]
+    const int64_t *foff = nullptr, *ioff = nullptr, *uoff = nullptr;
+    const int *front_idx = nullptr, *pull0 = nullptr, *pull1 = nullptr;
+    const double *F = nullptr;
+    double *U = nullptr;                                                  // update vectors [update_rows][TP]
+    const int2 *fwd_desc = nullptr, *bwd_desc = nullptr;                  // (node, first row / first column) per workgroup
+};
+
 // Layout of the device scalar block used by the PCG (all arrays have NC entries, NC <= 256).
 struct CgScalOffsets {
     static constexpr int NCMAX = 256;
@@ -122,6 +135,9 @@ int cg_apply_operator(Ctx *c, const double *x_node, double *y_node);  // y = K x
 int cg_finish_sharded(Ctx *c, const double *gathered);                // phi from all ranks' mode-space solutions
 int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes);
 int64_t cg_partials_needed(const Dev &d);   // doubles of Dev::partials the PCG uses
+int front_setup(Ctx *c, const dots_front_desc *desc);
+void front_release(Ctx *c);
+int front_solve(Ctx *c, const double *bhat, double *y, double *x);   // x = A^-1 bhat for every mode of the PCG view (y: scratch)
 int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int nb, int ept, int vt, int G);  // enqueue z = MG(r); z holds D^-1 r on entry
 int kkt_evaluate(Ctx *c, uint32_t mask, double *out);
 int objective_evaluate(Ctx *c, double *out);
@@ -154,6 +170,13 @@ struct Ctx {
     int use_mg = 1;
     int mg_tail_rows = 256;       // levels with at most this many rows run inside the single tail launch (DOTS_MG_TAIL_ROWS)
     int cg_graph_mg = -1;
+    FrontDev front{};             // multifrontal factor (n_nodes == 0: none)
+    int use_front = 0;
+    int front_fwd_ptr[66]{}, front_bwd_ptr[66]{};   // workgroup ranges of the tree levels in fwd_desc / bwd_desc
+    int front_fwd_rb[65]{}, front_bwd_cb[65]{};     // rows / columns per workgroup on each level
+    double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps)
+    void *front_allocs[24]{};
+    int n_front_allocs = 0;
     void *mg_allocs[160]{};
     int n_mg_allocs = 0;
     // constants of the KKT normalisation (solver_socp.py:303-313)

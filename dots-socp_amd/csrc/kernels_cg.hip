@@ -664,10 +664,11 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
     const bool sharded = MODAL && c->shard_count > 0;
     const bool owns_mode0 = !sharded || c->shard_begin == 0;
     if (MODAL && g.cg_ncol == 0) return 0;   // a rank without modes has nothing to solve
+    const bool direct = MODAL && c->use_front && c->front.n_nodes > 0;   // no warm start, no mean removal needed
     if (sharded) {
         const int gs = 1024;   // grid-stride; k_cg_bmean sums exactly this many partial sums
         hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.cg_b, g.cg_p0, owns_mode0 ? 1 : 0);
-        hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.phi, g.cg_x, 0);
+        if (!direct) hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.phi, g.cg_x, 0);
         b = g.cg_p0;
         const double mean_scale = (singular && owns_mode0) ? 1.0 / d.V : 0.0;
         hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, owns_mode0 ? gs : 0, g.cg_ncol, mean_scale);
@@ -675,14 +676,22 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
         if (MODAL) {
             // b^ = Q^T b (into p0 as scratch), x^ = Q^T phi (warm start in mode space)
             hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_b, d.cg_p0, 1);
-            hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.phi, d.cg_x, 0);
+            if (!direct) hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.phi, d.cg_x, 0);
             b = d.cg_p0;   // consumed by k_cg_r0 before iteration 0 (which reads no p_old: beta = 0) writes p1
         }
         const double mean_scale = !singular ? 0.0 : (MODAL ? 1.0 / d.V : 1.0 / ((double)d.V * (d.T + 1)));
         hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, gt, MODAL ? d.cg_ncol : 1, mean_scale);
     }
     DOTS_HIP(hipGetLastError());
-    int rc = cg_core<MODAL>(c, b, x, stats);
+    int rc;
+    if (direct) {
+        // direct solve: the two triangular sweeps of the multifrontal factor (kernels_front.hip)
+        rc = front_solve(c, b, g.cg_z, x);
+        c->last_cg_iters = 0;
+        if (stats) stats->cg_last_iterations = 0;
+    } else {
+        rc = cg_core<MODAL>(c, b, x, stats);
+    }
     if (rc) return rc;
     if (MODAL && !sharded) {
         hipLaunchKernelGGL((k_time_modes<false>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_x, d.phi, 0);
@@ -721,6 +730,24 @@ int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes) {
     const Dev &d = modal ? c->dcg : c->d;
     CgArgs a = make_args(c, modal);
     const size_t lds = cg_lds_bytes(a.cap, a.vt, a.nb);
+    if (which == 3) {   // both sweeps of the direct solve on whatever the vectors hold
+        if (!modal || c->front.n_nodes == 0) {
+            set_error("bench: no multifrontal factor on this context");
+            return DOTS_ERR_STATE;
+        }
+        int rcf = 0;
+        for (int i = 0; i < 2; ++i) rcf |= front_solve(c, d.cg_p0, d.cg_z, d.cg_x);
+        DOTS_HIP(hipEventRecord(c->ev[6], c->stream));
+        for (int i = 0; i < reps; ++i) rcf |= front_solve(c, d.cg_p0, d.cg_z, d.cg_x);
+        DOTS_HIP(hipEventRecord(c->ev[7], c->stream));
+        DOTS_HIP(hipEventSynchronize(c->ev[7]));
+        if (rcf) return rcf;
+        float tf = 0.f;
+        DOTS_HIP(hipEventElapsedTime(&tf, c->ev[6], c->ev[7]));
+        *ms = (double)tf / reps;
+        *bytes = c->front_bytes + 8.0 * (double)d.V * d.cg_ncol * 4.0;   // factor twice; b read, y written + read, x written
+        return 0;
+    }
     if (which == 2 && !a.mg) {
         set_error("bench: no multigrid hierarchy on this context");
         return DOTS_ERR_STATE;

@@ -1,0 +1,262 @@
+// Direct solve of the modal surface problems  (K + (sigma_a + eps) M) x_a = b_a  for all time modes a:
+// the two triangular sweeps of a multifrontal Cholesky factorisation (replaces the per-iteration
+// SuperLU solves of the reference, utils/laplacian_inverse_socp.py:46-60; the factor itself is built once
+// per solve by dots-socp_amd/frontal.py, as the reference builds its T+1 LU factors at :40-44).
+//
+// One nested-dissection tree is shared by all modes.  Node p eliminates n_p separator vertices and
+// touches b_p boundary vertices of its ancestors; its dense block per mode is
+//     F_p = [ L_pp^-1 ; G_p ],   G_p = A_bs A_ss^-1,   (n_p + b_p) x n_p,   stored [row][col][mode]
+// so that BOTH sweeps are batched dense matrix-vector products that stream F once, with the mode index
+// fastest (a wavefront reads two 256-byte runs per load at T = 31, like every other kernel of the path):
+//     forward   w   = b[sep_p] - (update rows pulled from the two children)
+//               y_p = L_pp^-1 w                    rows [0, n_p) of F_p (lower triangle only)
+//               u_p = (children's updates on bd_p) + G_p w          rows [n_p, n_p + b_p)
+//     backward  x_p = F_p^T [ y_p ; -x[bd_p] ]
+// Updates are PULLED by the parent from its children's buffers (pull0 / pull1 index maps), so nothing is
+// scattered and no atomics are needed: results are deterministic.  All nodes of one tree height are
+// independent: one launch per height and sweep, a workgroup = (node, block of rows | columns), the dot
+// products split over the workgroup's wave lanes that do not index the mode and folded through LDS.
+// HBM-bound: one solve reads sum_p (n_p (n_p + 1) / 2 + b_p n_p) * modes * 8 bytes twice and touches the
+// vectors (V * modes * 8 bytes) a handful of times.
+#include "dots_dev.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace dots {
+
+constexpr int FRONT_NB = 256;
+constexpr int FRONT_RB = 4;    // most rows (columns) of a node one workgroup handles
+
+// forward sweep of one tree height
+__global__ __launch_bounds__(FRONT_NB) void k_front_fwd(Dev d, FrontDev f, const int2 *__restrict__ desc, int rb, const double *__restrict__ bhat,
+                                                        double *__restrict__ Y) {
+    __shared__ double red[FRONT_RB * FRONT_NB];
+    const int2 ds = desc[blockIdx.x];
+    const int p = ds.x, row0 = ds.y;
+    const int sh = d.tp_shift, tid = threadIdx.x;
+    const int a = tid & (d.TP - 1), q = tid >> sh, Q = FRONT_NB >> sh;
+    const int n = f.node_n[p], m = n + f.node_b[p];
+    const int64_t io = f.ioff[p];
+    const int *__restrict__ idx = f.front_idx + io;
+    const int *__restrict__ pl0 = f.pull0 + io;
+    const int *__restrict__ pl1 = f.pull1 + io;
+    const int c0 = f.child[2 * p], c1 = f.child[2 * p + 1];
+    const double *__restrict__ U0 = c0 >= 0 ? f.U + (f.uoff[c0] << sh) : nullptr;
+    const double *__restrict__ U1 = c1 >= 0 ? f.U + (f.uoff[c1] << sh) : nullptr;
+    const double *__restrict__ Fp = f.F + (f.foff[p] << sh);
+    const bool live = a < d.cg_ncol;
+    const int nr = min(rb, m - row0);
+
+    double acc[FRONT_RB] = {0.0, 0.0, 0.0, 0.0};
+    // rows of L^-1 only need the columns j <= i: the block's last row bounds the loop
+    const int last = row0 + nr - 1;
+    const int jmax = last < n ? last + 1 : n;
+    if (live) {
+        for (int j = q; j < jmax; j += Q) {
+            double w = bhat[((int64_t)idx[j] << sh) + a];
+            if (U0) { const int k = pl0[j]; if (k >= 0) w -= U0[((int64_t)k << sh) + a]; }
+            if (U1) { const int k = pl1[j]; if (k >= 0) w -= U1[((int64_t)k << sh) + a]; }
+#pragma unroll
+            for (int r = 0; r < FRONT_RB; ++r) {
+                const int i = row0 + r;
+                if (r < nr && (i >= n || j <= i)) acc[r] += Fp[(((int64_t)i * n + j) << sh) + a] * w;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FRONT_RB; ++r) red[r * FRONT_NB + tid] = acc[r];
+    __syncthreads();
+    for (int r = q; r < nr && live; r += Q) {
+        double s = 0.0;
+        for (int k = 0; k < Q; ++k) s += red[r * FRONT_NB + (k << sh) + a];
+        const int i = row0 + r;
+        if (i < n) {
+            Y[((int64_t)idx[i] << sh) + a] = s;
+        } else {
+            if (U0) { const int k = pl0[i]; if (k >= 0) s += U0[((int64_t)k << sh) + a]; }
+            if (U1) { const int k = pl1[i]; if (k >= 0) s += U1[((int64_t)k << sh) + a]; }
+            f.U[((f.uoff[p] + (i - n)) << sh) + a] = s;
+        }
+    }
+}
+
+// backward sweep of one tree height
+__global__ __launch_bounds__(FRONT_NB) void k_front_bwd(Dev d, FrontDev f, const int2 *__restrict__ desc, int cb, const double *__restrict__ Y,
+                                                        double *X) {
+    __shared__ double red[FRONT_RB * FRONT_NB];
+    const int2 ds = desc[blockIdx.x];
+    const int p = ds.x, col0 = ds.y;
+    const int sh = d.tp_shift, tid = threadIdx.x;
+    const int a = tid & (d.TP - 1), q = tid >> sh, Q = FRONT_NB >> sh;
+    const int n = f.node_n[p], m = n + f.node_b[p];
+    const int *__restrict__ idx = f.front_idx + f.ioff[p];
+    const double *__restrict__ Fp = f.F + (f.foff[p] << sh);
+    const bool live = a < d.cg_ncol;
+    const int nc = min(cb, n - col0);
+
+    double acc[FRONT_RB] = {0.0, 0.0, 0.0, 0.0};
+    if (live) {
+        // column i of L^-1 is zero above the diagonal: start at the block's first column
+        for (int j = col0 + q; j < m; j += Q) {
+            const int64_t iv = ((int64_t)idx[j] << sh) + a;
+            const double v = j < n ? Y[iv] : -X[iv];      // X of boundary rows: written by launches of greater heights
+            const double *__restrict__ row = Fp + (((int64_t)j * n + col0) << sh) + a;
+#pragma unroll
+            for (int r = 0; r < FRONT_RB; ++r)
+                if (r < nc && j >= col0 + r) acc[r] += row[(int64_t)r << sh] * v;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FRONT_RB; ++r) red[r * FRONT_NB + tid] = acc[r];
+    __syncthreads();
+    for (int r = q; r < nc && live; r += Q) {
+        double s = 0.0;
+        for (int k = 0; k < Q; ++k) s += red[r * FRONT_NB + (k << sh) + a];
+        X[((int64_t)idx[col0 + r] << sh) + a] = s;
+    }
+}
+
+void front_release(Ctx *c) {
+    for (int i = 0; i < c->n_front_allocs; ++i) (void)hipFree(c->front_allocs[i]);
+    c->n_front_allocs = 0;
+    c->front = FrontDev{};
+    c->use_front = 0;
+    c->front_bytes = 0.0;
+}
+
+template <typename T>
+static int front_upload(Ctx *c, const T **out, const T *host, int64_t count) {
+    void *p = nullptr;
+    const size_t bytes = sizeof(T) * (size_t)std::max<int64_t>(count, 1);
+    DOTS_HIP(hipMalloc(&p, bytes));
+    if (c->n_front_allocs >= (int)(sizeof(c->front_allocs) / sizeof(c->front_allocs[0]))) {
+        (void)hipFree(p);
+        set_error("front allocation table full");
+        return DOTS_ERR_STATE;
+    }
+    c->front_allocs[c->n_front_allocs++] = p;
+    if (host) DOTS_HIP(hipMemcpyAsync(p, host, sizeof(T) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    else DOTS_HIP(hipMemsetAsync(p, 0, bytes, c->stream));
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    *out = (const T *)p;
+    return 0;
+}
+
+int front_setup(Ctx *c, const dots_front_desc *h) {
+    const Dev &d = c->dcg;
+    auto bad = [&](const char *what) {
+        set_error(std::string("front_setup: ") + what);
+        return (int)DOTS_ERR_ARGUMENT;
+    };
+    if (!h || h->n_nodes < 1 || h->n_levels < 1 || h->n_levels > 64) return bad("bad description");
+    if (!h->node_n || !h->node_b || !h->node_foff || !h->node_ioff || !h->node_uoff || !h->node_child || !h->front_idx || !h->pull0 ||
+        !h->pull1 || !h->level_ptr || !h->level_nodes || !h->values)
+        return bad("null array");
+    if (h->pitch != d.TP || h->n_modes != d.cg_ncol) return bad("pitch / mode count does not match the context");
+    // ---- index sanity: a wrong index would fault on the device -------------------------------------
+    const int nn = h->n_nodes;
+    int64_t fo = 0, io = 0, uo = 0, eliminated = 0;
+    double entries_read = 0.0;
+    for (int p = 0; p < nn; ++p) {
+        const int64_t n = h->node_n[p], b = h->node_b[p];
+        if (n < 0 || b < 0 || n + b < 1) return bad("node size");
+        if (h->node_foff[p] != fo || h->node_ioff[p] != io || h->node_uoff[p] != uo) return bad("node offsets are not the running sums");
+        for (int k = 0; k < 2; ++k) {
+            const int ch = h->node_child[2 * p + k];
+            if (ch < -1 || ch >= p) return bad("child index (nodes must be numbered children first)");
+        }
+        const int c0 = h->node_child[2 * p], c1 = h->node_child[2 * p + 1];
+        for (int64_t i = 0; i < n + b; ++i) {
+            const int v = h->front_idx[io + i];
+            if (v < 0 || v >= d.V) return bad("front vertex out of range");
+            const int k0 = h->pull0[io + i], k1 = h->pull1[io + i];
+            if (k0 < -1 || (k0 >= 0 && (c0 < 0 || k0 >= h->node_b[c0]))) return bad("pull0 out of range");
+            if (k1 < -1 || (k1 >= 0 && (c1 < 0 || k1 >= h->node_b[c1]))) return bad("pull1 out of range");
+        }
+        fo += (n + b) * n;
+        io += n + b;
+        uo += b;
+        eliminated += n;
+        entries_read += 0.5 * n * (n + 1) + (double)b * n;
+    }
+    if (fo != h->n_entries || io != h->n_front_rows || uo != h->update_rows || eliminated != d.V) return bad("totals do not match");
+    if (h->level_ptr[0] != 0 || h->level_ptr[h->n_levels] != nn) return bad("level_ptr");
+    std::vector<int> level_of(nn, -1);
+    for (int l = 0; l < h->n_levels; ++l) {
+        if (h->level_ptr[l + 1] < h->level_ptr[l]) return bad("level_ptr not monotone");
+        for (int k = h->level_ptr[l]; k < h->level_ptr[l + 1]; ++k) {
+            const int p = h->level_nodes[k];
+            if (p < 0 || p >= nn || level_of[p] != -1) return bad("level_nodes is not a permutation");
+            level_of[p] = l;
+        }
+    }
+    for (int p = 0; p < nn; ++p)
+        for (int k = 0; k < 2; ++k) {
+            const int ch = h->node_child[2 * p + k];
+            if (ch >= 0 && level_of[ch] >= level_of[p]) return bad("a child is not on a lower level than its parent");
+        }
+
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    front_release(c);
+    // ---- workgroup lists: (node, first row) per level for the forward sweep, (node, first column) backward
+    std::vector<int2> fwd, bwd;
+    for (int l = 0; l < h->n_levels; ++l) {
+        int64_t rows = 0, cols = 0;
+        for (int k = h->level_ptr[l]; k < h->level_ptr[l + 1]; ++k) {
+            const int p = h->level_nodes[k];
+            rows += h->node_n[p] + h->node_b[p];
+            cols += h->node_n[p];
+        }
+        auto block = [](int64_t total) { return total >= 4096 ? 4 : (total >= 2048 ? 2 : 1); };   // keep >= ~1000 workgroups where the level allows
+        const int rb = block(rows), cb = block(cols);
+        c->front_fwd_rb[l] = rb;
+        c->front_bwd_cb[l] = cb;
+        c->front_fwd_ptr[l] = (int)fwd.size();
+        c->front_bwd_ptr[l] = (int)bwd.size();
+        for (int k = h->level_ptr[l]; k < h->level_ptr[l + 1]; ++k) {
+            const int p = h->level_nodes[k];
+            for (int r = 0; r < h->node_n[p] + h->node_b[p]; r += rb) fwd.push_back(make_int2(p, r));
+            for (int r = 0; r < h->node_n[p]; r += cb) bwd.push_back(make_int2(p, r));
+        }
+    }
+    c->front_fwd_ptr[h->n_levels] = (int)fwd.size();
+    c->front_bwd_ptr[h->n_levels] = (int)bwd.size();
+
+    FrontDev f{};
+    f.n_nodes = nn;
+    f.n_levels = h->n_levels;
+    int rc;
+#define FUP(field, src, n) if ((rc = front_upload(c, &f.field, src, (int64_t)(n)))) { front_release(c); return rc; }
+    FUP(node_n, h->node_n, nn); FUP(node_b, h->node_b, nn); FUP(child, h->node_child, 2 * (int64_t)nn);
+    FUP(foff, h->node_foff, nn); FUP(ioff, h->node_ioff, nn); FUP(uoff, h->node_uoff, nn);
+    FUP(front_idx, h->front_idx, h->n_front_rows); FUP(pull0, h->pull0, h->n_front_rows); FUP(pull1, h->pull1, h->n_front_rows);
+    FUP(F, h->values, h->n_entries << d.tp_shift);
+    FUP(fwd_desc, fwd.data(), fwd.size()); FUP(bwd_desc, bwd.data(), bwd.size());
+    const double *u = nullptr;
+    if ((rc = front_upload<double>(c, &u, nullptr, std::max<int64_t>(h->update_rows, 1) << d.tp_shift))) { front_release(c); return rc; }
+    f.U = const_cast<double *>(u);
+#undef FUP
+    c->front = f;
+    c->use_front = 1;
+    c->front_bytes = 2.0 * entries_read * d.cg_ncol * sizeof(double);
+    return 0;
+}
+
+int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
+    const Dev &d = c->dcg;
+    const FrontDev &f = c->front;
+    if (f.n_nodes == 0) { set_error("front_solve: no factor installed"); return DOTS_ERR_STATE; }
+    for (int l = 0; l < f.n_levels; ++l) {
+        const int g = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
+        if (g > 0) hipLaunchKernelGGL(k_front_fwd, dim3(g), dim3(FRONT_NB), 0, c->stream, d, f, f.fwd_desc + c->front_fwd_ptr[l], c->front_fwd_rb[l], bhat, y);
+    }
+    for (int l = f.n_levels - 1; l >= 0; --l) {
+        const int g = c->front_bwd_ptr[l + 1] - c->front_bwd_ptr[l];
+        if (g > 0) hipLaunchKernelGGL(k_front_bwd, dim3(g), dim3(FRONT_NB), 0, c->stream, d, f, f.bwd_desc + c->front_bwd_ptr[l], c->front_bwd_cb[l], y, x);
+    }
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dots

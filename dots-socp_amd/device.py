@@ -270,6 +270,45 @@ class DeviceProblem:
         self.mg_summary = multigrid.hierarchy_summary(levels)
         return self.mg_summary
 
+    # ---- direct (multifrontal) solve of the modal problems
+    def setup_frontal(self, eps=0.0, leaf=None, mode_slice=None):
+        """Factorise K + (sigma_a + eps) M for this context's modes on one nested-dissection tree
+        (frontal.py) and install the factor: step 1 then runs two triangular sweeps instead of the PCG."""
+        import scipy.sparse as sp
+
+        from . import frontal
+
+        if self.lap_solver != "modal_pcg":
+            raise ValueError("the direct solve needs the modal solver")
+        p = self.plan
+        K = sp.csr_matrix((p.lap_val, p.lap_col, p.lap_rowptr), shape=(p.n_vertices, p.n_vertices))
+        diss = p.dissection if leaf is None else None     # the plan's own tree (reorder="nd") unless a leaf size is forced
+        if diss is None:
+            diss = frontal.nested_dissection(K.indptr, K.indices, p.vertices, leaf=leaf or 16)
+        if mode_slice is None:
+            mode_slice = self.mode_slice
+        sigma = p.time_eigs if mode_slice is None else p.time_eigs[mode_slice]
+        if sigma.size == 0:
+            return None
+        pitch = int(self.lib.dots_front_pitch(self._h))
+        ff = frontal.factorize(K, p.mass_vert, sigma + float(eps), diss, pitch=pitch)
+        d = _lib.FrontDesc()
+        d.n_nodes, d.n_levels, d.n_modes, d.pitch = ff.node_n.size, ff.level_ptr.size - 1, ff.n_modes, ff.pitch
+        d.n_front_rows, d.n_entries, d.update_rows = ff.front_idx.size, ff.values.shape[0], ff.update_rows
+        keep = [np.ascontiguousarray(a) for a in (ff.node_n, ff.node_b, ff.node_foff, ff.node_ioff, ff.node_uoff, ff.node_child,
+                                                   ff.front_idx, ff.pull0, ff.pull1, ff.level_ptr, ff.level_nodes, ff.values)]
+        d.node_n, d.node_b = _ptr(keep[0], C.c_int32), _ptr(keep[1], C.c_int32)
+        d.node_foff, d.node_ioff, d.node_uoff = _ptr(keep[2], C.c_int64), _ptr(keep[3], C.c_int64), _ptr(keep[4], C.c_int64)
+        d.node_child, d.front_idx = _ptr(keep[5], C.c_int32), _ptr(keep[6], C.c_int32)
+        d.pull0, d.pull1 = _ptr(keep[7], C.c_int32), _ptr(keep[8], C.c_int32)
+        d.level_ptr, d.level_nodes, d.values = _ptr(keep[9], C.c_int32), _ptr(keep[10], C.c_int32), _ptr(keep[11], C.c_double)
+        _lib.check(self.lib.dots_front_setup(self._h, C.byref(d)), "dots_front_setup")
+        self.front_summary = dict(ff.stats)
+        return self.front_summary
+
+    def enable_frontal(self, on=True):
+        _lib.check(self.lib.dots_front_enable(self._h, 1 if on else 0), "dots_front_enable")
+
     def enable_multigrid(self, on=True):
         _lib.check(self.lib.dots_mg_enable(self._h, 1 if on else 0), "dots_mg_enable")
 

@@ -1,0 +1,315 @@
+"""Host-side setup of the direct (multifrontal) Laplacian solve of step 1.
+
+The reference inverts the space-time Laplacian exactly: an eigen-decomposition in time followed by T+1
+sparse LU factorisations of the shifted surface operators ``K + (sigma_a + eps) M`` (SuperLU,
+``utils/laplacian_inverse_socp.py:11-61``).  This module builds the MI355X form of that algorithm: ONE
+nested-dissection elimination tree of the mesh graph shared by all time modes, and per tree node a small
+dense block per mode, laid out so that both triangular sweeps are batched dense matrix-vector products
+that stream the factor once from HBM with the mode index fastest (the device layout of every node array):
+
+    node p:  separator rows  sep_p  (n_p vertices, eliminated at p)
+             boundary rows   bd_p   (b_p vertices of ancestors' separators that the subtree touches)
+             F_p = [ L_pp^-1 ; A_bs A_ss^-1 ]   (n_p + b_p) x n_p   per mode, stored [row][col][mode]
+
+    forward  (leaves -> root, one launch per tree height):
+             w      = b[sep_p] - (updates pulled from the two children)
+             y_p    = L_pp^-1 w                                   rows 0..n_p of F_p
+             u_p    = (children's updates on bd_p) + G_p w        rows n_p.. of F_p      (pull form: no atomics)
+    backward (root -> leaves):   x_p = F_p^T [ y_p ; -x[bd_p] ]
+
+The numeric factorisation (dense frontal Cholesky, batched over the modes with numpy) runs once per solve
+on the host, as the reference's SuperLU factorisations do.  Nothing here is a fallback for the device
+path: the sweeps exist only as HIP kernels (csrc/kernels_front.hip).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.linalg.lapack import dtrtri as _trtri
+
+
+# ------------------------------------------------------------------------------------------------
+# nested dissection
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Dissection:
+    """Elimination tree.  Node ids are in post-order (children before parents; the root is last)."""
+    order: np.ndarray          # (V,) vertex eliminated at position k
+    sep_ptr: np.ndarray        # (n_nodes+1,) node p eliminates order[sep_ptr[p]:sep_ptr[p+1]]
+    child: np.ndarray          # (n_nodes, 2) children ids or -1
+    parent: np.ndarray         # (n_nodes,)
+    height: np.ndarray         # (n_nodes,) 0 for leaves
+
+    @property
+    def n_nodes(self):
+        return self.parent.size
+
+
+def _neighbour_ranges(indptr, rows):
+    """Concatenated CSR positions of `rows` and the local row number of each position."""
+    starts = indptr[rows]
+    lens = indptr[rows + 1] - starts
+    total = int(lens.sum())
+    first = np.cumsum(lens) - lens
+    local = np.repeat(np.arange(rows.size), lens)
+    pos = np.arange(total) - np.repeat(first, lens) + np.repeat(starts, lens)
+    return pos, local
+
+
+def nested_dissection(indptr, indices, coords, leaf=16) -> Dissection:
+    """Geometric nested dissection: a subset is cut at the median of its principal axis, the separator is
+    the smaller of the two one-sided vertex boundaries of the cut (so it is a separator of the GRAPH
+    whatever the embedding looks like); subsets of at most `leaf` vertices become dense leaves."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices, dtype=np.int64)
+    coords = np.asarray(coords, dtype=np.float64)
+    V = indptr.size - 1
+    mark = np.zeros(V, dtype=np.int8)
+    seps, childs = [], []
+
+    def cut(S):
+        X = coords[S]
+        X = X - X.mean(axis=0)
+        w, U = np.linalg.eigh(X.T @ X)
+        proj = X @ U[:, -1]
+        o = np.argsort(proj, kind="stable")
+        half = S.size // 2
+        A, B = S[o[:half]], S[o[half:]]
+        mark[A], mark[B] = 1, 2
+        pa, la = _neighbour_ranges(indptr, A)
+        sepA = A[np.bincount(la, weights=(mark[indices[pa]] == 2), minlength=A.size) > 0]
+        pb, lb = _neighbour_ranges(indptr, B)
+        sepB = B[np.bincount(lb, weights=(mark[indices[pb]] == 1), minlength=B.size) > 0]
+        mark[S] = 0
+        if sepA.size <= sepB.size:
+            A2 = np.setdiff1d(A, sepA, assume_unique=True)
+            return A2, B, sepA
+        B2 = np.setdiff1d(B, sepB, assume_unique=True)
+        return A, B2, sepB
+
+    def build(S):
+        if S.size <= leaf:
+            seps.append(S)
+            childs.append((-1, -1))
+            return len(seps) - 1
+        A, B, sep = cut(S)
+        if A.size == 0 or B.size == 0:      # degenerate cut (e.g. a thin strip): eliminate the subset densely
+            seps.append(S)
+            childs.append((-1, -1))
+            return len(seps) - 1
+        a = build(A)
+        b = build(B)
+        seps.append(sep)
+        childs.append((a, b))
+        return len(seps) - 1
+
+    import sys
+    old = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(old, 10000))
+    try:
+        build(np.arange(V, dtype=np.int64))
+    finally:
+        sys.setrecursionlimit(old)
+    n = len(seps)
+    child = np.asarray(childs, dtype=np.int32).reshape(n, 2)
+    parent = np.full(n, -1, dtype=np.int32)
+    height = np.zeros(n, dtype=np.int32)
+    for p in range(n):
+        for c in child[p]:
+            if c >= 0:
+                parent[c] = p
+                height[p] = max(height[p], height[c] + 1)
+    sep_ptr = np.zeros(n + 1, dtype=np.int64)
+    sep_ptr[1:] = np.cumsum([s.size for s in seps])
+    order = np.concatenate(seps)
+    assert order.size == V and np.array_equal(np.sort(order), np.arange(V))
+    return Dissection(order=order, sep_ptr=sep_ptr, child=child, parent=parent, height=height)
+
+
+# ------------------------------------------------------------------------------------------------
+# symbolic + numeric factorisation
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class FrontalFactor:
+    """Flat arrays of the device solver (see include/dots_socp_hip.h, dots_front_desc)."""
+    n_vertices: int
+    n_modes: int
+    pitch: int                 # doubles per (row, col) entry of F = modes padded to the device pitch
+    node_n: np.ndarray         # (n_nodes,) separator size
+    node_b: np.ndarray         # (n_nodes,) boundary size
+    node_foff: np.ndarray      # (n_nodes,) int64 offset of F_p in entries (row*col units, multiply by pitch)
+    node_ioff: np.ndarray      # (n_nodes,) int64 offset into front_idx / pull0 / pull1
+    node_uoff: np.ndarray      # (n_nodes,) int64 first row of u_p in the update buffer
+    node_child: np.ndarray     # (n_nodes, 2)
+    front_idx: np.ndarray      # vertex of every front row (separator rows first, then boundary rows)
+    pull0: np.ndarray          # position of the front row in child 0's boundary (or -1); same length as front_idx
+    pull1: np.ndarray
+    level_ptr: np.ndarray      # (n_levels+1,) into level_nodes
+    level_nodes: np.ndarray    # nodes sorted by height
+    values: np.ndarray         # F of all nodes, (sum m_p n_p, pitch)
+    update_rows: int           # rows of the update buffer
+    grounded: np.ndarray       # modes whose operator is singular (root pivot grounded)
+    stats: dict = field(default_factory=dict)
+
+
+def symbolic(diss: Dissection, indptr, indices):
+    """Boundary sets: bd_p = (adj(sep_p) U bd(children)) minus everything eliminated at or below p,
+    ordered by elimination position."""
+    V = diss.order.size
+    pos = np.empty(V, dtype=np.int64)
+    pos[diss.order] = np.arange(V)
+    bds = []
+    for p in range(diss.n_nodes):
+        sep = diss.order[diss.sep_ptr[p]:diss.sep_ptr[p + 1]]
+        last = diss.sep_ptr[p + 1]
+        pr, _ = _neighbour_ranges(indptr, sep)
+        cand = [indices[pr]]
+        for c in diss.child[p]:
+            if c >= 0:
+                cand.append(bds[c])
+        cand = np.unique(np.concatenate(cand))
+        cand = cand[pos[cand] >= last]
+        bds.append(cand[np.argsort(pos[cand], kind="stable")])
+    return bds, pos
+
+
+def _numeric(K_parts, mass, shifts, singular, diss, bds, node_foff, values, cols):
+    """Dense frontal Cholesky of the modes `cols` (a slice of the mode axis); writes values[:, cols]."""
+    indptr, indices, data = K_parts
+    V = indptr.size - 1
+    A = shifts.size
+    frontpos = np.full(V, -1, dtype=np.int64)
+    schur = {}
+    for p in range(diss.n_nodes):
+        sep = diss.order[diss.sep_ptr[p]:diss.sep_ptr[p + 1]]
+        bd = bds[p]
+        n, b = sep.size, bd.size
+        front = np.concatenate([sep, bd])
+        frontpos[front] = np.arange(n + b)
+        pr, loc = _neighbour_ranges(indptr, sep)
+        rows = frontpos[indices[pr]]
+        ok = rows >= 0
+        rows, loc, val = rows[ok], loc[ok], data[pr][ok]
+        # columns of the front that are eliminated here: A[front, sep]; the boundary block starts from the children
+        C = np.zeros((A, n + b, n))
+        C[:, rows, loc] = val[None, :]
+        ar = np.arange(n)
+        C[:, ar, ar] += shifts[:, None] * mass[sep][None, :]
+        Abb = np.zeros((A, b, b))
+        for c in diss.child[p]:
+            if c < 0:
+                continue
+            cm = frontpos[bds[c]]
+            Sc = schur.pop(c)
+            lo = cm < n                      # child boundary rows that are separator rows of p
+            ilo, ihi = np.flatnonzero(lo), np.flatnonzero(~lo)
+            C[:, cm[:, None], cm[ilo][None, :]] += Sc[:, :, ilo]
+            if ihi.size:
+                h = cm[ihi] - n
+                Abb[:, h[:, None], h[None, :]] += Sc[:, ihi[:, None], ihi[None, :]]
+        frontpos[front] = -1
+        if n == 0:      # empty separator (the cut fell between two components): the node only passes updates on
+            if b:
+                schur[p] = Abb
+            continue
+        Ass = np.ascontiguousarray(C[:, :n])
+        root = diss.parent[p] < 0
+        if root and singular.any():
+            Ass[singular, n - 1, :] = 0.0
+            Ass[singular, :, n - 1] = 0.0
+            Ass[singular, n - 1, n - 1] = 1.0
+        L = np.linalg.cholesky(Ass)
+        Linv = np.empty_like(L)
+        for a in range(A):
+            Linv[a] = _trtri(L[a], lower=1)[0]
+        if root and singular.any():
+            Linv[singular, n - 1, :] = 0.0
+        fo = node_foff[p]
+        out = values[fo:fo + (n + b) * n].reshape(n + b, n, -1)
+        out[:n, :, cols] = np.moveaxis(Linv, 0, -1)
+        if b:
+            Abs = np.ascontiguousarray(C[:, n:])
+            G = (Abs @ np.ascontiguousarray(np.swapaxes(Linv, 1, 2))) @ Linv
+            S = Abb - G @ np.ascontiguousarray(np.swapaxes(Abs, 1, 2))
+            schur[p] = 0.5 * (S + np.swapaxes(S, 1, 2))
+            out[n:, :, cols] = np.moveaxis(G, 0, -1)
+
+
+def factorize(K: sp.csr_matrix, mass, shifts, diss: Dissection, pitch=None, workers=None) -> FrontalFactor:
+    """Multifrontal Cholesky of K + shifts[a] * diag(mass) for all modes a (the modes are independent: they
+    are factorised in chunks on a thread pool; LAPACK/BLAS release the GIL)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    K = sp.csr_matrix(K)
+    K.sort_indices()
+    indptr, indices, data = K.indptr.astype(np.int64), K.indices.astype(np.int64), K.data.astype(np.float64)
+    mass = np.asarray(mass, dtype=np.float64)
+    shifts = np.asarray(shifts, dtype=np.float64)
+    A = shifts.size
+    P = int(pitch) if pitch is not None else A
+    V = K.shape[0]
+    bds, pos = symbolic(diss, indptr, indices)
+    nn = diss.n_nodes
+    node_n = np.diff(diss.sep_ptr).astype(np.int32)
+    node_b = np.asarray([b.size for b in bds], dtype=np.int32)
+    m = node_n.astype(np.int64) + node_b
+    node_foff = np.zeros(nn, dtype=np.int64)
+    node_foff[1:] = np.cumsum(m * node_n)[:-1]
+    node_ioff = np.zeros(nn, dtype=np.int64)
+    node_ioff[1:] = np.cumsum(m)[:-1]
+    node_uoff = np.zeros(nn, dtype=np.int64)
+    node_uoff[1:] = np.cumsum(node_b.astype(np.int64))[:-1]
+    total_f = int((m * node_n).sum())
+    front_idx = np.empty(int(m.sum()), dtype=np.int32)
+    pull = [np.full(front_idx.size, -1, dtype=np.int32), np.full(front_idx.size, -1, dtype=np.int32)]
+    frontpos = np.full(V, -1, dtype=np.int64)
+    for p in range(nn):
+        front = np.concatenate([diss.order[diss.sep_ptr[p]:diss.sep_ptr[p + 1]], bds[p]])
+        io = node_ioff[p]
+        front_idx[io:io + front.size] = front
+        frontpos[front] = np.arange(front.size)
+        for k, c in enumerate(diss.child[p]):
+            if c >= 0:
+                cm = frontpos[bds[c]]
+                pull[k][io + cm] = np.arange(cm.size, dtype=np.int32)
+        frontpos[front] = -1
+
+    scale = float(np.abs(K.diagonal()).max())
+    singular = np.abs(shifts) * float(mass.max()) <= 1e-13 * scale
+    values = np.zeros((total_f, P), dtype=np.float64)
+    if workers is None:
+        workers = max(1, min(A, (os.cpu_count() or 2) - 1, 16))
+    chunks = [c for c in np.array_split(np.arange(A), workers) if c.size]
+    parts = (indptr, indices, data)
+
+    def run(cols):
+        _numeric(parts, mass, shifts[cols], singular[cols], diss, bds, node_foff, values, cols)
+
+    if len(chunks) == 1:
+        run(chunks[0])
+    else:
+        try:
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=1)
+        except Exception:  # pragma: no cover
+            import contextlib
+            limit = contextlib.nullcontext()
+        with limit, ThreadPoolExecutor(len(chunks)) as ex:
+            list(ex.map(run, chunks))
+    order_by_h = np.argsort(diss.height, kind="stable").astype(np.int32)
+    n_levels = int(diss.height.max()) + 1
+    level_ptr = np.searchsorted(diss.height[order_by_h], np.arange(n_levels + 1)).astype(np.int32)
+    stats = {
+        "nodes": int(nn), "levels": n_levels, "leaf_rows_max": int(node_n[diss.height == 0].max()),
+        "root_rows": int(node_n[-1]), "empty_separators": int((node_n == 0).sum()), "max_front": int(m.max()), "factor_entries_per_mode": total_f,
+        "factor_bytes": int(total_f) * P * values.itemsize, "update_rows": int(node_b.sum()),
+    }
+    return FrontalFactor(
+        n_vertices=V, n_modes=A, pitch=P, node_n=node_n, node_b=node_b, node_foff=node_foff, node_ioff=node_ioff,
+        node_uoff=node_uoff, node_child=diss.child.astype(np.int32), front_idx=front_idx, pull0=pull[0], pull1=pull[1],
+        level_ptr=level_ptr, level_nodes=order_by_h, values=values, update_rows=int(node_b.sum()),
+        grounded=np.flatnonzero(singular).astype(np.int32), stats=stats,
+    )

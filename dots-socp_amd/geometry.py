@@ -40,6 +40,8 @@ class DevicePlan:
     time_modes: np.ndarray    # (T+1, T+1) Q[t, a]
     time_eigs: np.ndarray     # (T+1,) sigma_a >= 0
     area_mesh: float
+    vertices: np.ndarray | None = None    # (V,3) device numbering (used by the nested dissection of frontal.py)
+    dissection: object | None = None      # frontal.Dissection in device numbering when reorder == "nd"
 
 
 def hat_gradients(vertices, triangles):
@@ -110,7 +112,23 @@ def locality_order(K, triangles):
     return perm_v, perm_f
 
 
-def build_plan(n_time, geometry, reorder=True) -> DevicePlan:
+def dissection_order(K, vertices, triangles, leaf=16):
+    """Nested-dissection numbering (the elimination order of the direct solver, frontal.py): leaves are
+    compact patches of the surface, so it is also a locality-preserving numbering for the gathers."""
+    from . import frontal
+
+    diss = frontal.nested_dissection(K.indptr, K.indices, vertices, leaf=leaf)
+    perm_v = diss.order.astype(np.int64)
+    inv = np.empty_like(perm_v)
+    inv[perm_v] = np.arange(perm_v.size)
+    t_new = inv[np.asarray(triangles)]
+    perm_f = np.argsort(t_new.min(axis=1), kind="stable")
+    diss.order = np.arange(perm_v.size, dtype=np.int64)      # in the new numbering the order is the identity
+    return perm_v, perm_f, diss
+
+
+def build_plan(n_time, geometry, reorder=True, nd_leaf=16) -> DevicePlan:
+    """``reorder``: True / "rcm" reverse Cuthill-McKee, "nd" nested dissection (direct solver), False none."""
     vertices = np.asarray(geometry["vertices"], dtype=np.float64)
     triangles = np.asarray(geometry["triangles"]).astype(np.int64)
     mu0 = np.asarray(geometry["mu0"], dtype=np.float64)
@@ -121,10 +139,14 @@ def build_plan(n_time, geometry, reorder=True) -> DevicePlan:
     if mu0.shape != (V,) or mu1.shape != (V,):
         raise ValueError("mu0/mu1 must have one entry per vertex")
 
-    perm_v = perm_f = None
+    perm_v = perm_f = diss = None
     if reorder:
         area0, hat0 = hat_gradients(vertices, triangles)
-        perm_v, perm_f = locality_order(stiffness_matrix(V, triangles, area0, hat0), triangles)
+        K0 = stiffness_matrix(V, triangles, area0, hat0)
+        if reorder == "nd":
+            perm_v, perm_f, diss = dissection_order(K0, vertices, triangles, leaf=nd_leaf)
+        else:
+            perm_v, perm_f = locality_order(K0, triangles)
         inv = np.empty_like(perm_v)
         inv[perm_v] = np.arange(V)
         vertices = vertices[perm_v]
@@ -152,5 +174,5 @@ def build_plan(n_time, geometry, reorder=True) -> DevicePlan:
         mu0=c(mu0), mu1=c(mu1),
         perm_vert=None if perm_v is None else c(perm_v.astype(np.int32)),
         perm_tri=None if perm_f is None else c(perm_f.astype(np.int32)),
-        time_modes=c(Q), time_eigs=c(sigma), area_mesh=float(area.sum()),
+        time_modes=c(Q), time_eigs=c(sigma), area_mesh=float(area.sum()), vertices=c(vertices), dissection=diss,
     )

@@ -6,7 +6,9 @@ Same signature, return contract and iteration-by-iteration decisions as
 (``include/dots_socp_hip.h``), the state never leaves HBM between iterations and the host
 only sees scalars.  Extra keyword arguments (all optional) select device-side choices:
 
-    lap_solver   "modal_pcg" (default) or "spacetime_pcg"  -- how step 1's Laplacian is solved
+    lap_solver   how step 1's Laplacian is solved: "modal_direct" (time eigen-modes + multifrontal Cholesky
+                 sweeps, the reference's eigh + sparse-LU algorithm), "modal_pcg" (batched multigrid-PCG on the
+                 modes) or "spacetime_pcg" (Jacobi-PCG on the coupled operator)
     cg_tol       relative PCG tolerance (default 1e-8; see DESIGN.md for the parity budget)
     cg_max_iter  PCG iteration cap
     device       HIP device ordinal
@@ -69,8 +71,11 @@ class AlmSolver:
         self.n_time, self.nit, self.tol, self.time_limit = int(n_time), int(nit), tol, time_limit
         self.is_z_scaling, self.is_constant_scaling = is_z_scaling, is_constant_scaling
         self.check_kkt_step_by_step = check_kkt_step_by_step
-        self.dev = dev = DeviceProblem(n_time, geometry, lap_solver=lap_solver, device=device, reorder=reorder,
-                                       mode_shard=mode_shard)
+        direct = lap_solver == "modal_direct"
+        if direct and reorder is True:
+            reorder = "nd"      # the elimination order of the factor doubles as the locality numbering
+        self.dev = dev = DeviceProblem(n_time, geometry, lap_solver="modal_pcg" if direct else lap_solver, device=device,
+                                       reorder=reorder, mode_shard=mode_shard)
 
         p = dev.params
         self.r = 1.0
@@ -84,8 +89,10 @@ class AlmSolver:
         self._push()
         if preconditioner not in ("multigrid", "jacobi"):
             raise ValueError("preconditioner must be 'multigrid' or 'jacobi'")
-        self.mg_summary = None
-        if preconditioner == "multigrid" and lap_solver == "modal_pcg":
+        self.mg_summary = self.front_summary = None
+        if direct:
+            self.front_summary = dev.setup_frontal(eps=self.eps)
+        elif preconditioner == "multigrid" and lap_solver == "modal_pcg":
             self.mg_summary = dev.setup_multigrid(eps=self.eps, coarsest=mg_coarsest)
         init_solution = init_solution or {}
         self._upload_initial_state(init_solution)

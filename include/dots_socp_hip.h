@@ -253,10 +253,48 @@ typedef struct dots_mg_desc {
 int dots_mg_setup(dots_ctx *ctx, const dots_mg_desc *desc);
 int dots_mg_enable(dots_ctx *ctx, int on);   /* switch between multigrid (1) and Jacobi (0) preconditioning */
 
+/* ---- direct solve of the modal problems (replaces the T+1 SuperLU factorisations of
+ * laplacian_inverse_socp.py:40-61 and their per-iteration triangular solves, :46-60) ----------------
+ * Multifrontal Cholesky factor on one nested-dissection tree shared by all modes, built on the host
+ * (dots-socp_amd/frontal.py).  Nodes are numbered children-before-parents.  Node p eliminates n[p]
+ * separator vertices and touches b[p] boundary vertices of its ancestors; front_idx lists them
+ * (separator first) from ioff[p]; its dense block F_p = [L_pp^-1 ; A_bs A_ss^-1], (n+b) x n per mode,
+ * starts at row foff[p] of `values` ([n_entries][pitch], mode fastest).  pull0/pull1 (parallel to
+ * front_idx) give the position of a front row in the boundary of child 0 / 1 (or -1).  level_nodes
+ * lists the nodes by height, level_ptr delimits the heights.  With a factor installed and enabled,
+ * step 1 runs the two triangular sweeps instead of the PCG. */
+typedef struct dots_front_desc {
+    int32_t n_nodes;
+    int32_t n_levels;
+    int32_t n_modes;             /* modes the factor is given for (= T+1 on one GPU, mode_count when sharded) */
+    int32_t pitch;               /* doubles per entry of values; must equal the context's mode pitch */
+    int64_t n_front_rows;        /* length of front_idx, pull0, pull1 */
+    int64_t n_entries;           /* rows of values = sum over nodes of (n+b)*n */
+    int64_t update_rows;         /* sum of b */
+    const int32_t *node_n;
+    const int32_t *node_b;
+    const int64_t *node_foff;
+    const int64_t *node_ioff;
+    const int64_t *node_uoff;    /* first row of node p's update vector */
+    const int32_t *node_child;   /* [n_nodes][2], -1 = none */
+    const int32_t *front_idx;    /* device vertex numbering */
+    const int32_t *pull0;
+    const int32_t *pull1;
+    const int32_t *level_ptr;    /* [n_levels+1] */
+    const int32_t *level_nodes;  /* [n_nodes] */
+    const double *values;
+} dots_front_desc;
+
+int dots_front_setup(dots_ctx *ctx, const dots_front_desc *desc);
+int dots_front_enable(dots_ctx *ctx, int on);
+/* the mode pitch `values` must be laid out with (power of two >= the context's mode count, >= 8) */
+int dots_front_pitch(dots_ctx *ctx);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Launch the dominant kernel (the PCG operator application) `reps` times on the context's stream
  * between two hipEvents and return the average milliseconds per launch and the algorithmic bytes
  * one launch moves (DESIGN.md section "roofline"). */
+/* which: 0 PCG operator application, 1 PCG vector update, 2 one multigrid V-cycle, 3 both sweeps of the direct solve */
 int dots_bench_kernel(dots_ctx *ctx, int which, int reps, double *ms_per_launch, double *bytes_per_launch);
 
 /* device memory in use by the context, bytes */

@@ -1,0 +1,78 @@
+"""CPU tests of the host side of the direct solver (dots-socp_amd/frontal.py): the nested-dissection tree,
+the symbolic structure and the batched multifrontal factor, checked by running the device's sweeps in numpy
+(tests/frontal_cpu.py) against scipy's sparse solve."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+import frontal_cpu
+from dots_socp_amd import frontal, geometry, meshes
+
+
+def problem(name, reorder, **kw):
+    if name == "refplane":
+        v, t = meshes.plane(kw.get("n", 12))
+        g, _ = meshes.make_geometry(v, t, np.ones(v.shape[0]) / v.shape[0], np.ones(v.shape[0]) / v.shape[0])
+    else:
+        g, _ = meshes.example(name, **kw)
+    plan = geometry.build_plan(7, g, reorder=reorder, nd_leaf=kw.get("leaf", 8))
+    K = sp.csr_matrix((plan.lap_val, plan.lap_col, plan.lap_rowptr), shape=(plan.n_vertices,) * 2)
+    return plan, K
+
+
+CASES = [("sphere", dict(level=3)), ("refplane", dict(n=12)), ("torus", dict(nu=24, nv=16)), ("knot", dict(nu=60, nv=8))]
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+@pytest.mark.parametrize("reorder", [True, "nd"])
+def test_tree_and_structure(name, kw, reorder):
+    plan, K = problem(name, reorder, **kw)
+    V = plan.n_vertices
+    diss = plan.dissection if reorder == "nd" else frontal.nested_dissection(K.indptr, K.indices, plan.vertices, leaf=8)
+    if reorder == "nd":
+        assert np.array_equal(diss.order, np.arange(V))      # the device numbering IS the elimination order
+    assert np.array_equal(np.sort(diss.order), np.arange(V))
+    assert diss.parent[-1] == -1 and np.all(diss.parent[:-1] > np.arange(diss.n_nodes - 1))
+    # separator property: no edge joins the two subtrees of a node
+    owner = np.empty(V, dtype=np.int64)
+    for p in range(diss.n_nodes):
+        owner[diss.order[diss.sep_ptr[p]:diss.sep_ptr[p + 1]]] = p
+    anc = [set() for _ in range(diss.n_nodes)]
+    for p in range(diss.n_nodes - 1, -1, -1):
+        if diss.parent[p] >= 0:
+            anc[p] = anc[diss.parent[p]] | {int(diss.parent[p])}
+    coo = K.tocoo()
+    for i, j in zip(coo.row, coo.col):
+        a, b = int(owner[i]), int(owner[j])
+        assert a == b or a in anc[b] or b in anc[a]
+    bds, pos = frontal.symbolic(diss, K.indptr.astype(np.int64), K.indices.astype(np.int64))
+    for p in range(diss.n_nodes):
+        assert all(int(owner[v]) in anc[p] for v in bds[p])
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+@pytest.mark.parametrize("reorder", [False, "nd"])
+def test_factor_solves_every_mode(name, kw, reorder):
+    plan, K = problem(name, reorder, **kw)
+    diss = plan.dissection if reorder == "nd" else frontal.nested_dissection(K.indptr, K.indices, plan.vertices, leaf=5)
+    shifts = plan.time_eigs + 0.0
+    ff = frontal.factorize(K, plan.mass_vert, shifts, diss, pitch=8, workers=2)
+    assert ff.values.shape[1] == 8 and ff.grounded.tolist() == [0]
+    assert ff.stats["levels"] >= 3 and ff.level_ptr[-1] == ff.node_n.size
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal((plan.n_vertices, shifts.size))
+    b[:, 0] -= b[:, 0].mean()                         # the singular mode needs a right-hand side in the range
+    x = frontal_cpu.solve(ff, b)
+    M = sp.diags(plan.mass_vert)
+    for a in range(shifts.size):
+        A = (K + shifts[a] * M).tocsr()
+        assert np.max(np.abs(A @ x[:, a] - b[:, a])) < 1e-10 * np.max(np.abs(b[:, a])), a
+    # a regular mode agrees with SuperLU
+    xs = spl.spsolve((K + shifts[3] * M).tocsc(), b[:, 3])
+    assert np.max(np.abs(xs - x[:, 3])) < 1e-10 * np.max(np.abs(xs))
+    # eps > 0: nothing is grounded
+    ff2 = frontal.factorize(K, plan.mass_vert, shifts[:2] + 0.5, diss, workers=1)
+    assert ff2.grounded.size == 0
+    x2 = frontal_cpu.solve(ff2, b[:, :2])
+    assert np.max(np.abs((K + 0.5 * M) @ x2[:, 0] - b[:, 0])) < 1e-10 * np.max(np.abs(b[:, 0]))

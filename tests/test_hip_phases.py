@@ -97,17 +97,22 @@ def test_q_lambda_and_multipliers_a8_a9(fname, congestion):
 
 
 @pytest.mark.parametrize("fname", OPS)
-@pytest.mark.parametrize("lap_solver", ["spacetime_pcg", "modal_pcg", "modal_pcg+mg"])
+@pytest.mark.parametrize("lap_solver", ["spacetime_pcg", "modal_pcg", "modal_pcg+mg", "modal_pcg+direct", "modal_pcg+direct_nd"])
 @pytest.mark.parametrize("eps", [0.0, 1e-2])
 def test_laplacian_step_a2_a3(fname, lap_solver, eps):
     g = golden(fname)
-    s, dev = make_pair(g, lap_solver=lap_solver.split("+")[0], eps=eps)
+    s, dev = make_pair(g, lap_solver=lap_solver.split("+")[0], eps=eps, reorder="nd" if lap_solver.endswith("_nd") else True)
     if lap_solver.endswith("+mg"):
         summary = dev.setup_multigrid(eps=eps, coarsest=6)
         assert summary is not None and summary["levels"] >= 2
+    direct = "+direct" in lap_solver
+    if direct:    # tiny leaves: a tree of several levels even on the fixture meshes
+        nd = lap_solver.endswith("_nd")
+        summary = dev.setup_frontal(eps=eps, leaf=None if nd else 4)
+        assert summary["levels"] >= (2 if nd else 3)
     s.step_laplacian()
     st = dev.run_phase("laplacian")
-    assert st.cg_not_converged == 0 and st.cg_last_iterations > 0
+    assert st.cg_not_converged == 0 and (direct or st.cg_last_iterations > 0)
     got, want = dev.download("phi"), s.phi
     if eps == 0.0:
         got, want = remove_gauge(got, s.mass_v), remove_gauge(want, s.mass_v)
@@ -207,12 +212,14 @@ def test_full_iterations_track_oracle():
     g = golden("ops_ico1.npz")
     geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
     T = int(g["n_time"])
-    for lap in ("spacetime_pcg", "modal_pcg", "modal_pcg+mg"):
+    for lap in ("spacetime_pcg", "modal_pcg", "modal_pcg+mg", "modal_pcg+direct"):
         s = O.OracleSolver(T, geom)
         s.scale_z(2.0)
         dev = DeviceProblem(T, geom, lap_solver=lap.split("+")[0])
         if lap.endswith("+mg"):
             assert dev.setup_multigrid(coarsest=6)["levels"] >= 2
+        if lap.endswith("+direct"):
+            assert dev.setup_frontal(leaf=4)["levels"] >= 3
         dev.scale_z(2.0, 0.5, 2.0)
         dev.set_params(scale_z=2.0, const_d=2.0, norm_d=s.norm_d, cg_tol=1e-11)
         for _ in range(20):

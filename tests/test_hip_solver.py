@@ -69,10 +69,12 @@ def compare(g, sol, hist, rtol):
 
 
 @pytest.mark.parametrize("fname", SMALL)
-@pytest.mark.parametrize("lap_solver", ["modal_pcg+mg", "modal_pcg", "spacetime_pcg"])
+@pytest.mark.parametrize("lap_solver", ["modal_direct", "modal_pcg+mg", "modal_pcg", "spacetime_pcg"])
 def test_runs_match_reference(fname, lap_solver):
     g = golden(fname)
-    if lap_solver.endswith("+mg"):   # tiny meshes: force a multi-level hierarchy
+    if lap_solver == "modal_direct":
+        sol, hist = run_hip(g, lap_solver="modal_direct")
+    elif lap_solver.endswith("+mg"):   # tiny meshes: force a multi-level hierarchy
         sol, hist = run_hip(g, lap_solver="modal_pcg", preconditioner="multigrid", mg_coarsest=6, cg_tol=1e-11)
     else:
         sol, hist = run_hip(g, lap_solver=lap_solver, preconditioner="jacobi", cg_tol=1e-11)
