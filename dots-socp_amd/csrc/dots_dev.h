@@ -92,13 +92,23 @@ struct MgDev {
 // Direct (multifrontal) solve of the modal problems: the factor of dots-socp_amd/frontal.py on the device.
 // F_p = [L_pp^-1 ; A_bs A_ss^-1] of node p starts at F + (foff[p] << tp_shift), entry (i, j, mode) at
 // ((i * n_p + j) << tp_shift) + mode: the mode index is fastest, as in every node array.
+struct FrontNode {
+    int n, b;                 // separator rows eliminated here / boundary rows
+    int k0;                   // elimination index of the first separator row
+    int has_children;
+    int64_t foff;             // first (row, col) entry of F_p
+    int64_t woff;             // first row of this node's two update planes in W (plane k: child k), m rows each
+    int64_t parent_w;         // first row of the plane this node writes in its parent's W (-1: root)
+    int64_t bdoff;            // first boundary row of this node in bd_vertex / cmap
+};
 struct FrontDev {
     int n_nodes = 0, n_levels = 0;
-    const int *node_n = nullptr, *node_b = nullptr, *child = nullptr;       // child: [n_nodes][2]
-    const int64_t *foff = nullptr, *ioff = nullptr, *uoff = nullptr;
-    const int *front_idx = nullptr, *pull0 = nullptr, *pull1 = nullptr;
+    const FrontNode *nodes = nullptr;
+    const int *vmap = nullptr;            // elimination index -> device vertex; nullptr when the device numbering is the elimination order
+    const int *bd_vertex = nullptr;       // device vertex of every boundary row
+    const int *cmap = nullptr;            // position of every boundary row in the parent's front
     const double *F = nullptr;
-    double *U = nullptr;                                                  // update vectors [update_rows][TP]
+    double *W = nullptr;                  // update planes [rows][TP]; entries no child writes stay zero
     const int2 *fwd_desc = nullptr, *bwd_desc = nullptr;                  // (node, first row / first column) per workgroup
 };
 
@@ -174,6 +184,7 @@ struct Ctx {
     int use_front = 0;
     int front_fwd_ptr[66]{}, front_bwd_ptr[66]{};   // workgroup ranges of the tree levels in fwd_desc / bwd_desc
     int front_fwd_rb[65]{}, front_bwd_cb[65]{};     // rows / columns per workgroup on each level
+    int front_fwd_nb[65]{}, front_bwd_nb[65]{};     // threads per workgroup on each level (256, or 1024 where a level has few rows)
     double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps)
     void *front_allocs[24]{};
     int n_front_allocs = 0;

@@ -25,27 +25,29 @@
 
 namespace dots {
 
-constexpr int FRONT_NB = 256;
 constexpr int FRONT_RB = 4;    // most rows (columns) of a node one workgroup handles
 
-// forward sweep of one tree height
-__global__ __launch_bounds__(FRONT_NB) void k_front_fwd(Dev d, FrontDev f, const int2 *__restrict__ desc, int rb, const double *__restrict__ bhat,
-                                                        double *__restrict__ Y) {
-    __shared__ double red[FRONT_RB * FRONT_NB];
+struct FrontArgs {
+    int sh, TP, ncol;          // mode pitch (log2, value) and live modes
+};
+
+__device__ __forceinline__ int64_t front_row(const FrontDev &f, int k) { return f.vmap ? f.vmap[k] : k; }
+
+// forward sweep of one tree height.  Workgroup = (node, rb rows); thread = (mode a, part q of the dot product).
+template <int NB>
+__global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const int2 *__restrict__ desc, int rb, const double *__restrict__ bhat,
+                                                  double *__restrict__ Y) {
+    __shared__ double red[FRONT_RB * NB];
     const int2 ds = desc[blockIdx.x];
-    const int p = ds.x, row0 = ds.y;
-    const int sh = d.tp_shift, tid = threadIdx.x;
-    const int a = tid & (d.TP - 1), q = tid >> sh, Q = FRONT_NB >> sh;
-    const int n = f.node_n[p], m = n + f.node_b[p];
-    const int64_t io = f.ioff[p];
-    const int *__restrict__ idx = f.front_idx + io;
-    const int *__restrict__ pl0 = f.pull0 + io;
-    const int *__restrict__ pl1 = f.pull1 + io;
-    const int c0 = f.child[2 * p], c1 = f.child[2 * p + 1];
-    const double *__restrict__ U0 = c0 >= 0 ? f.U + (f.uoff[c0] << sh) : nullptr;
-    const double *__restrict__ U1 = c1 >= 0 ? f.U + (f.uoff[c1] << sh) : nullptr;
-    const double *__restrict__ Fp = f.F + (f.foff[p] << sh);
-    const bool live = a < d.cg_ncol;
+    const FrontNode nd = f.nodes[ds.x];
+    const int row0 = ds.y;
+    const int sh = g.sh, tid = threadIdx.x;
+    const int a = tid & (g.TP - 1), q = tid >> sh, Q = NB >> sh;
+    const int n = nd.n, m = n + nd.b;
+    const double *__restrict__ Fp = f.F + (nd.foff << sh) + a;
+    const double *__restrict__ W0 = f.W + (nd.woff << sh) + a;         // child 0's plane; child 1's is m rows further
+    const int64_t plane = (int64_t)m << sh;
+    const bool live = a < g.ncol;
     const int nr = min(rb, m - row0);
 
     double acc[FRONT_RB] = {0.0, 0.0, 0.0, 0.0};
@@ -54,66 +56,66 @@ __global__ __launch_bounds__(FRONT_NB) void k_front_fwd(Dev d, FrontDev f, const
     const int jmax = last < n ? last + 1 : n;
     if (live) {
         for (int j = q; j < jmax; j += Q) {
-            double w = bhat[((int64_t)idx[j] << sh) + a];
-            if (U0) { const int k = pl0[j]; if (k >= 0) w -= U0[((int64_t)k << sh) + a]; }
-            if (U1) { const int k = pl1[j]; if (k >= 0) w -= U1[((int64_t)k << sh) + a]; }
+            double w = bhat[(front_row(f, nd.k0 + j) << sh) + a];
+            if (nd.has_children) w -= W0[(int64_t)j << sh] + W0[plane + ((int64_t)j << sh)];
 #pragma unroll
             for (int r = 0; r < FRONT_RB; ++r) {
                 const int i = row0 + r;
-                if (r < nr && (i >= n || j <= i)) acc[r] += Fp[(((int64_t)i * n + j) << sh) + a] * w;
+                if (r < nr && (i >= n || j <= i)) acc[r] += Fp[((int64_t)i * n + j) << sh] * w;
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < FRONT_RB; ++r) red[r * FRONT_NB + tid] = acc[r];
+    for (int r = 0; r < FRONT_RB; ++r) red[r * NB + tid] = acc[r];
     __syncthreads();
     for (int r = q; r < nr && live; r += Q) {
         double s = 0.0;
-        for (int k = 0; k < Q; ++k) s += red[r * FRONT_NB + (k << sh) + a];
+        for (int k = 0; k < Q; ++k) s += red[r * NB + (k << sh) + a];
         const int i = row0 + r;
         if (i < n) {
-            Y[((int64_t)idx[i] << sh) + a] = s;
-        } else {
-            if (U0) { const int k = pl0[i]; if (k >= 0) s += U0[((int64_t)k << sh) + a]; }
-            if (U1) { const int k = pl1[i]; if (k >= 0) s += U1[((int64_t)k << sh) + a]; }
-            f.U[((f.uoff[p] + (i - n)) << sh) + a] = s;
+            Y[(front_row(f, nd.k0 + i) << sh) + a] = s;
+        } else {   // update row: carry the children's contributions on, hand the sum to the parent's plane
+            if (nd.has_children) s += W0[(int64_t)i << sh] + W0[plane + ((int64_t)i << sh)];
+            f.W[((nd.parent_w + f.cmap[nd.bdoff + (i - n)]) << sh) + a] = s;
         }
     }
 }
 
-// backward sweep of one tree height
-__global__ __launch_bounds__(FRONT_NB) void k_front_bwd(Dev d, FrontDev f, const int2 *__restrict__ desc, int cb, const double *__restrict__ Y,
-                                                        double *X) {
-    __shared__ double red[FRONT_RB * FRONT_NB];
+// backward sweep of one tree height.  Workgroup = (node, cb columns).
+template <int NB>
+__global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const int2 *__restrict__ desc, int cb, const double *__restrict__ Y,
+                                                  double *X) {
+    __shared__ double red[FRONT_RB * NB];
     const int2 ds = desc[blockIdx.x];
-    const int p = ds.x, col0 = ds.y;
-    const int sh = d.tp_shift, tid = threadIdx.x;
-    const int a = tid & (d.TP - 1), q = tid >> sh, Q = FRONT_NB >> sh;
-    const int n = f.node_n[p], m = n + f.node_b[p];
-    const int *__restrict__ idx = f.front_idx + f.ioff[p];
-    const double *__restrict__ Fp = f.F + (f.foff[p] << sh);
-    const bool live = a < d.cg_ncol;
+    const FrontNode nd = f.nodes[ds.x];
+    const int col0 = ds.y;
+    const int sh = g.sh, tid = threadIdx.x;
+    const int a = tid & (g.TP - 1), q = tid >> sh, Q = NB >> sh;
+    const int n = nd.n, m = n + nd.b;
+    const double *__restrict__ Fp = f.F + (nd.foff << sh) + a;
+    const int *__restrict__ bdv = f.bd_vertex + nd.bdoff;
+    const bool live = a < g.ncol;
     const int nc = min(cb, n - col0);
 
     double acc[FRONT_RB] = {0.0, 0.0, 0.0, 0.0};
     if (live) {
         // column i of L^-1 is zero above the diagonal: start at the block's first column
         for (int j = col0 + q; j < m; j += Q) {
-            const int64_t iv = ((int64_t)idx[j] << sh) + a;
-            const double v = j < n ? Y[iv] : -X[iv];      // X of boundary rows: written by launches of greater heights
-            const double *__restrict__ row = Fp + (((int64_t)j * n + col0) << sh) + a;
+            // X of boundary rows: written by the launches of greater heights
+            const double v = j < n ? Y[(front_row(f, nd.k0 + j) << sh) + a] : -X[((int64_t)bdv[j - n] << sh) + a];
+            const double *__restrict__ row = Fp + (((int64_t)j * n + col0) << sh);
 #pragma unroll
             for (int r = 0; r < FRONT_RB; ++r)
                 if (r < nc && j >= col0 + r) acc[r] += row[(int64_t)r << sh] * v;
         }
     }
 #pragma unroll
-    for (int r = 0; r < FRONT_RB; ++r) red[r * FRONT_NB + tid] = acc[r];
+    for (int r = 0; r < FRONT_RB; ++r) red[r * NB + tid] = acc[r];
     __syncthreads();
     for (int r = q; r < nc && live; r += Q) {
         double s = 0.0;
-        for (int k = 0; k < Q; ++k) s += red[r * FRONT_NB + (k << sh) + a];
-        X[((int64_t)idx[col0 + r] << sh) + a] = s;
+        for (int k = 0; k < Q; ++k) s += red[r * NB + (k << sh) + a];
+        X[(front_row(f, nd.k0 + col0 + r) << sh) + a] = s;
     }
 }
 
@@ -199,7 +201,68 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
 
     DOTS_HIP(hipStreamSynchronize(c->stream));
     front_release(c);
-    // ---- workgroup lists: (node, first row) per level for the forward sweep, (node, first column) backward
+    // ---- node records, elimination order, update planes ------------------------------------------------
+    std::vector<FrontNode> nodes((size_t)nn);
+    std::vector<int> vmap((size_t)d.V), bd_vertex((size_t)std::max<int64_t>(h->update_rows, 1)), cmap((size_t)std::max<int64_t>(h->update_rows, 1), 0);
+    std::vector<char> seen((size_t)d.V, 0);
+    int64_t wrows = 0;
+    {
+        int k0 = 0;
+        bool identity = true;
+        for (int p = 0; p < nn; ++p) {
+            FrontNode &nd = nodes[(size_t)p];
+            nd.n = h->node_n[p];
+            nd.b = h->node_b[p];
+            nd.k0 = k0;
+            nd.foff = h->node_foff[p];
+            nd.bdoff = h->node_uoff[p];
+            nd.parent_w = -1;
+            nd.has_children = (h->node_child[2 * p] >= 0 || h->node_child[2 * p + 1] >= 0) ? 1 : 0;
+            nd.woff = nd.has_children ? wrows : 0;
+            if (nd.has_children) wrows += 2 * (int64_t)(nd.n + nd.b);
+            const int64_t io = h->node_ioff[p];
+            for (int i = 0; i < nd.n; ++i) {
+                const int v = h->front_idx[io + i];
+                if (seen[(size_t)v]) return bad("a vertex is eliminated twice");
+                seen[(size_t)v] = 1;
+                vmap[(size_t)(k0 + i)] = v;
+                identity = identity && v == k0 + i;
+            }
+            for (int i = 0; i < nd.b; ++i) bd_vertex[(size_t)(nd.bdoff + i)] = h->front_idx[io + nd.n + i];
+            k0 += nd.n;
+        }
+        // the plane a child writes and where its boundary rows sit in the parent's front (from the pull maps)
+        for (int p = 0; p < nn; ++p) {
+            const FrontNode &nd = nodes[(size_t)p];
+            const int64_t io = h->node_ioff[p];
+            const int m = nd.n + nd.b;
+            for (int k = 0; k < 2; ++k) {
+                const int ch = h->node_child[2 * p + k];
+                if (ch < 0) continue;
+                FrontNode &cn = nodes[(size_t)ch];
+                if (cn.parent_w != -1) return bad("a node has two parents");
+                cn.parent_w = nd.woff + (int64_t)k * m;
+                const int32_t *pull = k == 0 ? h->pull0 : h->pull1;
+                std::vector<char> got((size_t)cn.b, 0);
+                for (int fpos = 0; fpos < m; ++fpos) {
+                    const int r = pull[io + fpos];
+                    if (r < 0) continue;
+                    if (got[(size_t)r]) return bad("a child boundary row is pulled twice");
+                    got[(size_t)r] = 1;
+                    cmap[(size_t)(cn.bdoff + r)] = fpos;
+                }
+                for (int r = 0; r < cn.b; ++r)
+                    if (!got[(size_t)r]) return bad("a child boundary row is not pulled by its parent");
+            }
+        }
+        for (int p = 0; p < nn; ++p)
+            if (nodes[(size_t)p].parent_w == -1 && nodes[(size_t)p].b != 0) return bad("a node without parent has boundary rows");
+        if (identity) vmap.clear();
+    }
+
+    // ---- workgroup lists: (node, first row) per level for the forward sweep, (node, first column) backward.
+    // Levels with many rows: 256-thread workgroups of up to 4 rows; the few large nodes near the root: one row
+    // per 1024-thread workgroup, so that the long dot products are split 4x finer.
     std::vector<int2> fwd, bwd;
     for (int l = 0; l < h->n_levels; ++l) {
         int64_t rows = 0, cols = 0;
@@ -212,6 +275,8 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         const int rb = block(rows), cb = block(cols);
         c->front_fwd_rb[l] = rb;
         c->front_bwd_cb[l] = cb;
+        c->front_fwd_nb[l] = (rows < 1024 && d.TP <= 256) ? 1024 : 256;
+        c->front_bwd_nb[l] = (cols < 1024 && d.TP <= 256) ? 1024 : 256;
         c->front_fwd_ptr[l] = (int)fwd.size();
         c->front_bwd_ptr[l] = (int)bwd.size();
         for (int k = h->level_ptr[l]; k < h->level_ptr[l + 1]; ++k) {
@@ -228,14 +293,14 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     f.n_levels = h->n_levels;
     int rc;
 #define FUP(field, src, n) if ((rc = front_upload(c, &f.field, src, (int64_t)(n)))) { front_release(c); return rc; }
-    FUP(node_n, h->node_n, nn); FUP(node_b, h->node_b, nn); FUP(child, h->node_child, 2 * (int64_t)nn);
-    FUP(foff, h->node_foff, nn); FUP(ioff, h->node_ioff, nn); FUP(uoff, h->node_uoff, nn);
-    FUP(front_idx, h->front_idx, h->n_front_rows); FUP(pull0, h->pull0, h->n_front_rows); FUP(pull1, h->pull1, h->n_front_rows);
+    FUP(nodes, nodes.data(), nn);
+    if (!vmap.empty()) FUP(vmap, vmap.data(), d.V);
+    FUP(bd_vertex, bd_vertex.data(), bd_vertex.size()); FUP(cmap, cmap.data(), cmap.size());
     FUP(F, h->values, h->n_entries << d.tp_shift);
-    FUP(fwd_desc, fwd.data(), fwd.size()); FUP(bwd_desc, bwd.data(), bwd.size());
-    const double *u = nullptr;
-    if ((rc = front_upload<double>(c, &u, nullptr, std::max<int64_t>(h->update_rows, 1) << d.tp_shift))) { front_release(c); return rc; }
-    f.U = const_cast<double *>(u);
+    FUP(fwd_desc, fwd.data(), std::max<size_t>(fwd.size(), 1)); FUP(bwd_desc, bwd.data(), std::max<size_t>(bwd.size(), 1));
+    const double *w = nullptr;
+    if ((rc = front_upload<double>(c, &w, nullptr, std::max<int64_t>(wrows, 1) << d.tp_shift))) { front_release(c); return rc; }
+    f.W = const_cast<double *>(w);
 #undef FUP
     c->front = f;
     c->use_front = 1;
@@ -247,13 +312,22 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
     const Dev &d = c->dcg;
     const FrontDev &f = c->front;
     if (f.n_nodes == 0) { set_error("front_solve: no factor installed"); return DOTS_ERR_STATE; }
+    const FrontArgs g{d.tp_shift, d.TP, d.cg_ncol};
     for (int l = 0; l < f.n_levels; ++l) {
-        const int g = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
-        if (g > 0) hipLaunchKernelGGL(k_front_fwd, dim3(g), dim3(FRONT_NB), 0, c->stream, d, f, f.fwd_desc + c->front_fwd_ptr[l], c->front_fwd_rb[l], bhat, y);
+        const int n = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
+        if (n <= 0) continue;
+        if (c->front_fwd_nb[l] == 1024)
+            hipLaunchKernelGGL((k_front_fwd<1024>), dim3(n), dim3(1024), 0, c->stream, g, f, f.fwd_desc + c->front_fwd_ptr[l], c->front_fwd_rb[l], bhat, y);
+        else
+            hipLaunchKernelGGL((k_front_fwd<256>), dim3(n), dim3(256), 0, c->stream, g, f, f.fwd_desc + c->front_fwd_ptr[l], c->front_fwd_rb[l], bhat, y);
     }
     for (int l = f.n_levels - 1; l >= 0; --l) {
-        const int g = c->front_bwd_ptr[l + 1] - c->front_bwd_ptr[l];
-        if (g > 0) hipLaunchKernelGGL(k_front_bwd, dim3(g), dim3(FRONT_NB), 0, c->stream, d, f, f.bwd_desc + c->front_bwd_ptr[l], c->front_bwd_cb[l], y, x);
+        const int n = c->front_bwd_ptr[l + 1] - c->front_bwd_ptr[l];
+        if (n <= 0) continue;
+        if (c->front_bwd_nb[l] == 1024)
+            hipLaunchKernelGGL((k_front_bwd<1024>), dim3(n), dim3(1024), 0, c->stream, g, f, f.bwd_desc + c->front_bwd_ptr[l], c->front_bwd_cb[l], y, x);
+        else
+            hipLaunchKernelGGL((k_front_bwd<256>), dim3(n), dim3(256), 0, c->stream, g, f, f.bwd_desc + c->front_bwd_ptr[l], c->front_bwd_cb[l], y, x);
     }
     DOTS_HIP(hipGetLastError());
     return 0;
