@@ -83,7 +83,7 @@ class FrontDesc(C.Structure):
         ("n_front_rows", C.c_int64), ("n_entries", C.c_int64), ("update_rows", C.c_int64),
         ("node_n", _i32p), ("node_b", _i32p), ("node_foff", C.POINTER(C.c_int64)), ("node_ioff", C.POINTER(C.c_int64)),
         ("node_uoff", C.POINTER(C.c_int64)), ("node_child", _i32p), ("front_idx", _i32p), ("pull0", _i32p), ("pull1", _i32p),
-        ("level_ptr", _i32p), ("level_nodes", _i32p), ("values", _f64p),
+        ("level_ptr", _i32p), ("level_nodes", _i32p), ("values", _f64p), ("grounded", _i32p),
     ]
 
 

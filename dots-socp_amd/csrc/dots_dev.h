@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/dots_socp_hip.h"
 
@@ -100,6 +101,10 @@ struct FrontNode {
     int64_t woff;             // first row of this node's two update planes in W (plane k: child k), m rows each
     int64_t parent_w;         // first row of the plane this node writes in its parent's W (-1: root)
     int64_t bdoff;            // first boundary row of this node in bd_vertex / cmap
+    // used by the numeric factorisation only (kernels_factor.hip)
+    int c0, c1;               // children (-1: none)
+    int64_t ioff;             // first front row in the pull maps
+    int64_t soff;             // first entry of the b x b Schur complement
 };
 struct FrontDev {
     int n_nodes = 0, n_levels = 0;
@@ -147,6 +152,7 @@ int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes);
 int64_t cg_partials_needed(const Dev &d);   // doubles of Dev::partials the PCG uses
 int front_setup(Ctx *c, const dots_front_desc *desc);
 void front_release(Ctx *c);
+int front_factorize(Ctx *c, const dots_front_desc *desc, FrontDev &f, const std::vector<FrontNode> &nodes, double *T, const int *grounded_host);
 int front_solve(Ctx *c, const double *bhat, double *y, double *x);   // x = A^-1 bhat for every mode of the PCG view (y: scratch)
 int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int nb, int ept, int vt, int G);  // enqueue z = MG(r); z holds D^-1 r on entry
 int kkt_evaluate(Ctx *c, uint32_t mask, double *out);

@@ -153,7 +153,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     };
     if (!h || h->n_nodes < 1 || h->n_levels < 1 || h->n_levels > 64) return bad("bad description");
     if (!h->node_n || !h->node_b || !h->node_foff || !h->node_ioff || !h->node_uoff || !h->node_child || !h->front_idx || !h->pull0 ||
-        !h->pull1 || !h->level_ptr || !h->level_nodes || !h->values)
+        !h->pull1 || !h->level_ptr || !h->level_nodes || (!h->values && !h->grounded))
         return bad("null array");
     if (h->pitch != d.TP || h->n_modes != d.cg_ncol) return bad("pitch / mode count does not match the context");
     // ---- index sanity: a wrong index would fault on the device -------------------------------------
@@ -208,6 +208,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     int64_t wrows = 0;
     {
         int k0 = 0;
+        int64_t soff = 0;
         bool identity = true;
         for (int p = 0; p < nn; ++p) {
             FrontNode &nd = nodes[(size_t)p];
@@ -217,6 +218,11 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             nd.foff = h->node_foff[p];
             nd.bdoff = h->node_uoff[p];
             nd.parent_w = -1;
+            nd.c0 = h->node_child[2 * p];
+            nd.c1 = h->node_child[2 * p + 1];
+            nd.ioff = h->node_ioff[p];
+            nd.soff = soff;
+            soff += (int64_t)nd.b * nd.b;
             nd.has_children = (h->node_child[2 * p] >= 0 || h->node_child[2 * p + 1] >= 0) ? 1 : 0;
             nd.woff = nd.has_children ? wrows : 0;
             if (nd.has_children) wrows += 2 * (int64_t)(nd.n + nd.b);
@@ -296,7 +302,16 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     FUP(nodes, nodes.data(), nn);
     if (!vmap.empty()) FUP(vmap, vmap.data(), d.V);
     FUP(bd_vertex, bd_vertex.data(), bd_vertex.size()); FUP(cmap, cmap.data(), cmap.size());
-    FUP(F, h->values, h->n_entries << d.tp_shift);
+    if (h->values) {
+        FUP(F, h->values, h->n_entries << d.tp_shift);
+    } else {   // numeric factorisation on the device (kernels_factor.hip)
+        const double *t = nullptr;
+        if ((rc = front_upload<double>(c, &t, nullptr, h->n_entries << d.tp_shift))) { front_release(c); return rc; }
+        std::vector<int> grounded((size_t)d.TP, 0);
+        for (int a = 0; a < h->n_modes; ++a) grounded[(size_t)a] = h->grounded[a] ? 1 : 0;
+        if ((rc = front_factorize(c, h, f, nodes, const_cast<double *>(t), grounded.data()))) { front_release(c); return rc; }
+        f.F = t;
+    }
     FUP(fwd_desc, fwd.data(), std::max<size_t>(fwd.size(), 1)); FUP(bwd_desc, bwd.data(), std::max<size_t>(bwd.size(), 1));
     const double *w = nullptr;
     if ((rc = front_upload<double>(c, &w, nullptr, std::max<int64_t>(wrows, 1) << d.tp_shift))) { front_release(c); return rc; }

@@ -271,9 +271,10 @@ class DeviceProblem:
         return self.mg_summary
 
     # ---- direct (multifrontal) solve of the modal problems
-    def setup_frontal(self, eps=0.0, leaf=None, mode_slice=None):
+    def setup_frontal(self, eps=0.0, leaf=None, mode_slice=None, numeric="device"):
         """Factorise K + (sigma_a + eps) M for this context's modes on one nested-dissection tree
-        (frontal.py) and install the factor: step 1 then runs two triangular sweeps instead of the PCG."""
+        (frontal.py) and install the factor: step 1 then runs two triangular sweeps instead of the PCG.
+        ``numeric``: "device" (HIP kernels, the default) or "host" (numpy reference, small meshes only)."""
         import scipy.sparse as sp
 
         from . import frontal
@@ -291,12 +292,19 @@ class DeviceProblem:
         if sigma.size == 0:
             return None
         pitch = int(self.lib.dots_front_pitch(self._h))
-        ff = frontal.factorize(K, p.mass_vert, sigma + float(eps), diss, pitch=pitch)
+        if numeric not in ("device", "host"):
+            raise ValueError("numeric must be 'device' or 'host'")
+        self.set_params(eps=float(eps))      # the device factorisation reads eps from the context
+        ff = frontal.factorize(K, p.mass_vert, sigma + float(eps), diss, pitch=pitch, numeric=numeric == "host")
         d = _lib.FrontDesc()
         d.n_nodes, d.n_levels, d.n_modes, d.pitch = ff.node_n.size, ff.level_ptr.size - 1, ff.n_modes, ff.pitch
-        d.n_front_rows, d.n_entries, d.update_rows = ff.front_idx.size, ff.values.shape[0], ff.update_rows
+        d.n_front_rows, d.n_entries, d.update_rows = ff.front_idx.size, ff.stats["factor_entries_per_mode"], ff.update_rows
+        flags = np.zeros(ff.n_modes, dtype=np.int32)
+        flags[ff.grounded] = 1
         keep = [np.ascontiguousarray(a) for a in (ff.node_n, ff.node_b, ff.node_foff, ff.node_ioff, ff.node_uoff, ff.node_child,
-                                                   ff.front_idx, ff.pull0, ff.pull1, ff.level_ptr, ff.level_nodes, ff.values)]
+                                                   ff.front_idx, ff.pull0, ff.pull1, ff.level_ptr, ff.level_nodes)]
+        keep.append(None if ff.values is None else np.ascontiguousarray(ff.values))
+        d.grounded = _ptr(flags, C.c_int32)
         d.node_n, d.node_b = _ptr(keep[0], C.c_int32), _ptr(keep[1], C.c_int32)
         d.node_foff, d.node_ioff, d.node_uoff = _ptr(keep[2], C.c_int64), _ptr(keep[3], C.c_int64), _ptr(keep[4], C.c_int64)
         d.node_child, d.front_idx = _ptr(keep[5], C.c_int32), _ptr(keep[6], C.c_int32)

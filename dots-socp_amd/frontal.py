@@ -237,9 +237,11 @@ def _numeric(K_parts, mass, shifts, singular, diss, bds, node_foff, values, cols
             out[n:, :, cols] = np.moveaxis(G, 0, -1)
 
 
-def factorize(K: sp.csr_matrix, mass, shifts, diss: Dissection, pitch=None, workers=None) -> FrontalFactor:
-    """Multifrontal Cholesky of K + shifts[a] * diag(mass) for all modes a (the modes are independent: they
-    are factorised in chunks on a thread pool; LAPACK/BLAS release the GIL)."""
+def factorize(K: sp.csr_matrix, mass, shifts, diss: Dissection, pitch=None, workers=1, numeric=True) -> FrontalFactor:
+    """Symbolic structure of the multifrontal factor of K + shifts[a] * diag(mass) on the tree `diss` and,
+    with ``numeric=True``, its values computed on the host with numpy (a reference for the device
+    factorisation of csrc/kernels_factor.hip, which is what the solver uses: ``numeric=False`` leaves
+    ``values`` None)."""
     import os
     from concurrent.futures import ThreadPoolExecutor
 
@@ -279,10 +281,10 @@ def factorize(K: sp.csr_matrix, mass, shifts, diss: Dissection, pitch=None, work
 
     scale = float(np.abs(K.diagonal()).max())
     singular = np.abs(shifts) * float(mass.max()) <= 1e-13 * scale
-    values = np.zeros((total_f, P), dtype=np.float64)
+    values = np.zeros((total_f, P), dtype=np.float64) if numeric else None
     if workers is None:
         workers = max(1, min(A, (os.cpu_count() or 2) - 1, 16))
-    chunks = [c for c in np.array_split(np.arange(A), workers) if c.size]
+    chunks = [c for c in np.array_split(np.arange(A), workers) if c.size] if numeric else []
     parts = (indptr, indices, data)
 
     def run(cols):
@@ -290,7 +292,7 @@ def factorize(K: sp.csr_matrix, mass, shifts, diss: Dissection, pitch=None, work
 
     if len(chunks) == 1:
         run(chunks[0])
-    else:
+    elif chunks:
         try:
             from threadpoolctl import threadpool_limits
             limit = threadpool_limits(limits=1)
@@ -305,7 +307,7 @@ def factorize(K: sp.csr_matrix, mass, shifts, diss: Dissection, pitch=None, work
     stats = {
         "nodes": int(nn), "levels": n_levels, "leaf_rows_max": int(node_n[diss.height == 0].max()),
         "root_rows": int(node_n[-1]), "empty_separators": int((node_n == 0).sum()), "max_front": int(m.max()), "factor_entries_per_mode": total_f,
-        "factor_bytes": int(total_f) * P * values.itemsize, "update_rows": int(node_b.sum()),
+        "factor_bytes": int(total_f) * P * 8, "update_rows": int(node_b.sum()),
     }
     return FrontalFactor(
         n_vertices=V, n_modes=A, pitch=P, node_n=node_n, node_b=node_b, node_foff=node_foff, node_ioff=node_ioff,

@@ -282,7 +282,9 @@ typedef struct dots_front_desc {
     const int32_t *pull1;
     const int32_t *level_ptr;    /* [n_levels+1] */
     const int32_t *level_nodes;  /* [n_nodes] */
-    const double *values;
+    const double *values;        /* the factor, or NULL: factorise K + (sigma_a + eps) M on the device (eps from dots_params) */
+    const int32_t *grounded;     /* [n_modes] 1: the mode's operator is singular (its last root pivot is grounded);
+                                    read when values == NULL */
 } dots_front_desc;
 
 int dots_front_setup(dots_ctx *ctx, const dots_front_desc *desc);

@@ -97,7 +97,7 @@ def test_q_lambda_and_multipliers_a8_a9(fname, congestion):
 
 
 @pytest.mark.parametrize("fname", OPS)
-@pytest.mark.parametrize("lap_solver", ["spacetime_pcg", "modal_pcg", "modal_pcg+mg", "modal_pcg+direct", "modal_pcg+direct_nd"])
+@pytest.mark.parametrize("lap_solver", ["spacetime_pcg", "modal_pcg", "modal_pcg+mg", "modal_pcg+direct", "modal_pcg+direct_host", "modal_pcg+direct_nd"])
 @pytest.mark.parametrize("eps", [0.0, 1e-2])
 def test_laplacian_step_a2_a3(fname, lap_solver, eps):
     g = golden(fname)
@@ -108,7 +108,7 @@ def test_laplacian_step_a2_a3(fname, lap_solver, eps):
     direct = "+direct" in lap_solver
     if direct:    # tiny leaves: a tree of several levels even on the fixture meshes
         nd = lap_solver.endswith("_nd")
-        summary = dev.setup_frontal(eps=eps, leaf=None if nd else 4)
+        summary = dev.setup_frontal(eps=eps, leaf=None if nd else 4, numeric="host" if lap_solver.endswith("_host") else "device")
         assert summary["levels"] >= (2 if nd else 3)
     s.step_laplacian()
     st = dev.run_phase("laplacian")
