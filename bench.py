@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="sphere10k", choices=sorted(WORKLOADS))
-    ap.add_argument("--lap-solver", default="modal_pcg", choices=["modal_direct", "modal_pcg", "spacetime_pcg"])
+    ap.add_argument("--lap-solver", default="modal_direct", choices=["modal_direct", "modal_pcg", "spacetime_pcg"])
     ap.add_argument("--preconditioner", default="multigrid", choices=["multigrid", "jacobi"])
     ap.add_argument("--cg-tol", type=float, default=None)
     ap.add_argument("--mg-coarsest", type=int, default=None, help="rows of the dense coarsest multigrid level (default: solver default)")
@@ -133,8 +133,10 @@ def main():
             dist.init_process_group(backend=backend)
         from dots_socp_amd.distributed import ShardedAlmSolver, TorchComm
 
+        if args.lap_solver == "spacetime_pcg":
+            raise SystemExit("--gpus N>1 shards the time modes: use --lap-solver modal_direct or modal_pcg")
         alm = ShardedAlmSolver(n_time, geom, comm=TorchComm(), congestion=congestion, nit=args.warmup + args.steps + 8,
-                               tol=1e-30, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner,
+                               tol=1e-30, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner, lap_solver=args.lap_solver,
                                time_limit=float("inf"), reorder=not args.no_reorder, **mg_kw)
     else:
         alm = AlmSolver(n_time, geom, congestion=congestion, nit=args.warmup + args.steps + 8, tol=1e-30,
@@ -226,8 +228,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {wl['example']} mesh V={V} F={F}, ntime={n_time}, congestion={congestion}, "
-                        f"cg_tol={cg_tol:g}, lap_solver={args.lap_solver if world == 1 else 'modal_pcg (mode-sharded)'}, "
-                        f"preconditioner={args.preconditioner}",
+                        f"lap_solver={args.lap_solver}{'' if world == 1 else ' (mode-sharded)'}"
+                        + ("" if args.lap_solver == "modal_direct" else f", cg_tol={cg_tol:g}, preconditioner={args.preconditioner}"),
             "unknowns": V * (n_time + 1), "state_bytes": 8 * ((n_time + 1) * V + 7 * n_time * V + 6 * (n_time + 1) * F + 36 * n_time * F),
             "device_bytes": dev_bytes, "pcg_iterations_per_step": cg_per_it,
             "step_seconds": steps_time,

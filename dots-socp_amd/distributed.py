@@ -134,7 +134,9 @@ class ShardedAlmSolver(AlmSolver):
             comm = TorchComm()
         self.comm = comm
         kw.setdefault("cg_tol", DEFAULT_CG_TOL)
-        kw["lap_solver"] = "modal_pcg"
+        kw.setdefault("lap_solver", "modal_direct")
+        if kw["lap_solver"] not in ("modal_direct", "modal_pcg"):
+            raise ValueError("the sharded solver works on the time modes: lap_solver must be 'modal_direct' or 'modal_pcg'")
         super().__init__(n_time, geometry, device=device, mode_shard=(comm.rank, comm.size), **kw)
         elems = self.dev.shard_elems()
         dev = torch.device(buffer_device) if buffer_device is not None else torch.device("cuda", device)

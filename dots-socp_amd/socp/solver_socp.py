@@ -6,7 +6,7 @@ Same signature, return contract and iteration-by-iteration decisions as
 (``include/dots_socp_hip.h``), the state never leaves HBM between iterations and the host
 only sees scalars.  Extra keyword arguments (all optional) select device-side choices:
 
-    lap_solver   how step 1's Laplacian is solved: "modal_direct" (time eigen-modes + multifrontal Cholesky
+    lap_solver   how step 1's Laplacian is solved: "modal_direct" (default; time eigen-modes + multifrontal Cholesky
                  sweeps, the reference's eigh + sparse-LU algorithm), "modal_pcg" (batched multigrid-PCG on the
                  modes) or "spacetime_pcg" (Jacobi-PCG on the coupled operator)
     cg_tol       relative PCG tolerance (default 1e-8; see DESIGN.md for the parity budget)
@@ -64,7 +64,7 @@ class AlmSolver:
 
     def __init__(self, n_time, geometry, congestion=0.0, nit=1000, eps=0.0, tol=1e-4, tau=1.90, is_z_scaling=True,
                  is_constant_scaling=False, check_kkt_step_by_step=False, init_solution=None, tol_checkpoints=None,
-                 time_limit=1000, lap_solver="modal_pcg", cg_tol=DEFAULT_CG_TOL, cg_max_iter=20000, device=0, reorder=True,
+                 time_limit=1000, lap_solver="modal_direct", cg_tol=DEFAULT_CG_TOL, cg_max_iter=20000, device=0, reorder=True,
                  preconditioner="multigrid", mg_coarsest=256, mode_shard=None):
         self.tol_checkpoints = _validate_checkpoints(tol_checkpoints, tol)
         self.checkpoint_solutions = []
@@ -344,7 +344,7 @@ def solver_socp(
         tol_checkpoints=None,
         time_limit=1000,
         *,
-        lap_solver="modal_pcg",
+        lap_solver="modal_direct",
         cg_tol=DEFAULT_CG_TOL,
         cg_max_iter=20000,
         device=0,

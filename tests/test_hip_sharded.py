@@ -49,8 +49,9 @@ def run_ranks(n_ranks, fn):
     return out
 
 
+@pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("n_ranks", [2, 3, 4])
-def test_sharded_laplacian_equals_single_context(n_ranks):
+def test_sharded_laplacian_equals_single_context(n_ranks, direct):
     """One ALM iteration through begin / gather / end on n_ranks contexts == dots_step on one context."""
     import torch
 
@@ -67,6 +68,8 @@ def test_sharded_laplacian_equals_single_context(n_ranks):
         for k, v in state.items():
             d.upload(k, v)
         d.set_params(r=1.3, scale_z=2.0, const_d=2.0, cg_tol=1e-12)
+        if direct:
+            d.setup_frontal(leaf=4)
     single.step(1)
     elems = devs[0].shard_elems()
     sends = [torch.zeros(elems, dtype=torch.float64, device="cuda") for _ in devs]
@@ -89,10 +92,13 @@ def test_sharded_laplacian_equals_single_context(n_ranks):
 
 
 @pytest.mark.parametrize("fname,n_ranks,mg", [
-    ("run_ico2_T15_cong_tol1e-3.npz", 2, True),
-    ("run_ico2_T15_cong_tol1e-3.npz", 4, False),
-    ("run_torus_T7_tol1e-4.npz", 3, True),
-    ("run_refplane4_T8_tol1e-3.npz", 2, False),
+    ("run_ico2_T15_cong_tol1e-3.npz", 2, "mg"),
+    ("run_ico2_T15_cong_tol1e-3.npz", 4, "jacobi"),
+    ("run_ico2_T15_cong_tol1e-3.npz", 3, "direct"),
+    ("run_torus_T7_tol1e-4.npz", 3, "mg"),
+    ("run_torus_T7_tol1e-4.npz", 2, "direct"),
+    ("run_refplane4_T8_tol1e-3.npz", 2, "jacobi"),
+    ("run_refplane4_T8_tol1e-3.npz", 4, "direct"),
 ])
 def test_sharded_runs_match_reference(fname, n_ranks, mg):
     """Whole solves on n_ranks 'GPUs': every rank stops at the reference's iteration with its cost and KKT."""
@@ -100,7 +106,10 @@ def test_sharded_runs_match_reference(fname, n_ranks, mg):
 
     g = golden(fname)
     kw = {k[3:]: (g[k].tolist() if g[k].ndim else g[k].item()) for k in g.files if k.startswith("kw_")}
-    kw.update(cg_tol=1e-11, preconditioner="multigrid" if mg else "jacobi", mg_coarsest=6)
+    if mg == "direct":
+        kw.update(lap_solver="modal_direct")
+    else:
+        kw.update(lap_solver="modal_pcg", cg_tol=1e-11, preconditioner="multigrid" if mg == "mg" else "jacobi", mg_coarsest=6)
 
     def rank_main(comm):
         return solver_socp_sharded(int(g["n_time"]), geom_of(g), comm=comm, device=0, **kw)
@@ -128,8 +137,8 @@ def test_more_ranks_than_modes():
     geom, _ = meshes.example("sphere", level=1)
     stride, parts = mode_partition(5, 8)
     assert stride == 1 and [c for _, c in parts] == [1, 1, 1, 1, 1, 0, 0, 0]
-    ref_sol, ref_hist = solver_socp(4, geom, nit=25, tol=1e-12, preconditioner="jacobi")
-    results = run_ranks(8, lambda comm: solver_socp_sharded(4, geom, comm=comm, nit=25, tol=1e-12, preconditioner="jacobi"))
+    ref_sol, ref_hist = solver_socp(4, geom, nit=25, tol=1e-12)
+    results = run_ranks(8, lambda comm: solver_socp_sharded(4, geom, comm=comm, nit=25, tol=1e-12))
     for sol, hist in results:
         assert np.allclose(hist.history["Transportation cost"], ref_hist.history["Transportation cost"], rtol=1e-8, equal_nan=True)
         assert np.max(np.abs(sol["mu"] - ref_sol["mu"])) < 1e-7 * np.max(np.abs(ref_sol["mu"]))
