@@ -125,6 +125,11 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     UP(cptr, p->corner_ptr, V + 1);
     UP(cidx, p->corner_idx, nC);
     UP(c_D, cD.data(), nC);
+    {
+        std::vector<double> fkD((size_t)nC);
+        for (int j = 0; j < nC; ++j) fkD[(size_t)p->corner_idx[j]] = cD[(size_t)j];
+        UP(fk_D, fkD.data(), nC);
+    }
     UP(c_gA, cgA.data(), nC * 3);
     UP(c_area, cArea.data(), nC);
     UP(rowptr, p->lap_rowptr, V + 1);
@@ -160,6 +165,7 @@ static int build(Ctx *c, const dots_problem_desc *p) {
         c->shard_stride = p->mode_stride;
     }
     if ((rc = dev_alloc(c, &d.cg_b, nnode))) return rc;
+    if ((rc = dev_alloc(c, &d.lamc, nnode))) return rc;
     if (!sharded) {
         double **cgv[6] = {&d.cg_r, &d.cg_z, &d.cg_p0, &d.cg_p1, &d.cg_Ap, &d.cg_x};
         for (auto q : cgv)
@@ -246,9 +252,10 @@ static int run_iteration_end(Ctx *c, const double *gathered, dots_step_stats *st
     int rc;
     DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
     if ((rc = cg_finish_sharded(c, gathered))) return rc;
-    if ((rc = launch_soc_projection(c))) return rc;
+    if ((rc = launch_soc_projection(c, 1))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[3], c->stream));
-    if ((rc = launch_q_lambda_mult(c))) return rc;
+    if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
+    c->zmid_stale = c->step_skip_zmid;
     DOTS_HIP(hipEventRecord(c->ev[4], c->stream));
     DOTS_HIP(hipEventSynchronize(c->ev[4]));
     if (st) {
@@ -263,25 +270,31 @@ static int run_iteration_end(Ctx *c, const double *gathered, dots_step_stats *st
 
 static int run_iteration(Ctx *c, dots_step_stats *st) {
     int rc;
+    if (!st) {   // asynchronous: enqueue only (the direct solver needs no host round trip); nothing is timed
+        if ((rc = launch_rhs(c))) return rc;
+        if ((rc = cg_solve(c, nullptr))) return rc;
+        if ((rc = launch_soc_projection(c, 1))) return rc;
+        c->zmid_stale = c->step_skip_zmid;
+        return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
+    }
     DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
     if ((rc = launch_rhs(c))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
     if ((rc = cg_solve(c, st))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
-    if ((rc = launch_soc_projection(c))) return rc;
+    if ((rc = launch_soc_projection(c, 1))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[3], c->stream));
-    if ((rc = launch_q_lambda_mult(c))) return rc;
+    if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
+    c->zmid_stale = c->step_skip_zmid;
     DOTS_HIP(hipEventRecord(c->ev[4], c->stream));
     DOTS_HIP(hipEventSynchronize(c->ev[4]));
-    if (st) {
-        float t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); st->ms_rhs += t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); st->ms_laplacian += t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[3])); st->ms_soc += t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[3], c->ev[4])); st->ms_q_lambda_multiplier += t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[4])); st->ms_total += t;
-        st->alm_iterations += 1;
-    }
+    float t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); st->ms_rhs += t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); st->ms_laplacian += t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[3])); st->ms_soc += t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[3], c->ev[4])); st->ms_q_lambda_multiplier += t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[4])); st->ms_total += t;
+    st->alm_iterations += 1;
     return 0;
 }
 
@@ -398,12 +411,14 @@ int dots_upload(dots_ctx *c, int id, const double *host, int64_t count) {
     DOTS_HIP(hipMemcpyAsync(c->stage, host, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
     if ((rc = launch_to_device_layout(c, id, c->stage))) return rc;
     DOTS_HIP(hipStreamSynchronize(c->stream));
+    if (id == DOTS_Z_MID) c->zmid_stale = 0;
     return 0;
 }
 int dots_download(dots_ctx *c, int id, double *host, int64_t count) {
     int rc = check(c);
     if (rc) return rc;
     if (id < 0 || id >= DOTS_N_ARRAYS || !host || count != array_count_host(c->d, id)) { set_error("download: bad array id or element count"); return DOTS_ERR_ARGUMENT; }
+    if (id == DOTS_Z_MID && c->zmid_stale) { set_error("download: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
     if ((rc = launch_from_device_layout(c, id, c->stage))) return rc;
     DOTS_HIP(hipMemcpyAsync(host, c->stage, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     DOTS_HIP(hipStreamSynchronize(c->stream));
@@ -452,8 +467,16 @@ int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
     dots_step_stats local;
     memset(&local, 0, sizeof local);
     for (int i = 0; i < n_iters; ++i)
-        if ((rc = run_iteration(c, &local))) return rc;
+        if ((rc = run_iteration(c, stats ? &local : nullptr))) return rc;
     if (stats) *stats = local;
+    return 0;
+}
+
+int dots_step_flags(dots_ctx *c, uint32_t flags) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (flags & ~(uint32_t)DOTS_STEP_SKIP_Z_MID) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
+    c->step_skip_zmid = (flags & DOTS_STEP_SKIP_Z_MID) ? 1 : 0;
     return 0;
 }
 
@@ -467,7 +490,7 @@ int dots_run_phase(dots_ctx *c, int phase, dots_step_stats *stats) {
             if ((rc = launch_rhs(c))) return rc;
             if ((rc = cg_solve(c, &local))) return rc;
             break;
-        case DOTS_PHASE_SOC_PROJECTION: rc = launch_soc_projection(c); break;
+        case DOTS_PHASE_SOC_PROJECTION: rc = launch_soc_projection(c); c->zmid_stale = 0; break;
         case DOTS_PHASE_Q_LAMBDA_MULT: rc = launch_q_lambda_mult(c); break;
         default: set_error("unknown phase"); return DOTS_ERR_ARGUMENT;
     }
@@ -482,6 +505,7 @@ int dots_kkt(dots_ctx *c, uint32_t mask, double *out) {
     if (rc) return rc;
     if (!out || (mask >> DOTS_N_KKT)) { set_error("kkt: bad mask or null output"); return DOTS_ERR_ARGUMENT; }
     if (!mask) return 0;
+    if (c->zmid_stale && (mask & (1u << DOTS_KKT_PRIM_Z))) { set_error("kkt: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
     return kkt_evaluate(c, mask, out);
 }
 int dots_objective(dots_ctx *c, double *out) {
@@ -515,6 +539,7 @@ int dots_norm_square(dots_ctx *c, int id, int part, double *out) {
     int rc = check(c);
     if (rc) return rc;
     if (id < 0 || id >= DOTS_N_ARRAYS || !out || part < 0 || part > 2) { set_error("norm_square: bad argument"); return DOTS_ERR_ARGUMENT; }
+    if (id == DOTS_Z_MID && c->zmid_stale) { set_error("norm_square: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
     return norm_square(c, id, part, out);
 }
 

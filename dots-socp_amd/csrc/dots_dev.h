@@ -51,6 +51,7 @@ struct Dev {
     const double *c_D;       // [3F]  sqrt(area_f / mass_v) per corner-list entry
     const double *c_gA;      // [3F][3] hat gradient * area_f per corner-list entry
     const double *c_area;    // [3F]  area_f per corner-list entry
+    const double *fk_D;      // [3F]  the same sqrt(area_f / mass_v), indexed by corner f*3+k
     const int *rowptr;       // [V+1]
     const int *col;          // [nnz]
     const double *val;       // [nnz]
@@ -61,6 +62,7 @@ struct Dev {
     const double *sigma;     // [T+1] or null
     // state
     double *phi, *A, *B, *lam, *zf, *zm, *ze, *mu, *E, *bf, *bm, *be;
+    double *lamc;            // [V][TP] cone multiplier of the last projection (z_mid = lamc/D * pre-image, rebuilt in steps 2+3)
     // PCG workspace (node layout)
     double *cg_b, *cg_r, *cg_z, *cg_p0, *cg_p1, *cg_Ap, *cg_x;
     double *partials;        // [MAX_SUMS or NC][n partial blocks]
@@ -136,9 +138,9 @@ constexpr int FLAG_TOTAL = CgScalOffsets::NCMAX + 8;
 struct Ctx;
 
 // ---- launch wrappers implemented in the kernel files (all asynchronous on ctx stream) ----
-int launch_soc_projection(Ctx *c);
+int launch_soc_projection(Ctx *c, int zmid_mode = 0);   // 0: write z_mid; 1: write only the cone multiplier
 int launch_rhs(Ctx *c);
-int launch_q_lambda_mult(Ctx *c);
+int launch_q_lambda_mult(Ctx *c, int zmid_mode = 0);    // 0: read z_mid; 1: rebuild it from the multiplier and store it; 2: rebuild, do not store
 int launch_adjust_penalty(Ctx *c, double factor);
 int launch_scale_z(Ctx *c, double z_mul, double beta_mul, double sz_new);
 int launch_scale_array(Ctx *c, int array_id, double factor);
@@ -186,6 +188,8 @@ struct Ctx {
     int use_mg = 1;
     int mg_tail_rows = 256;       // levels with at most this many rows run inside the single tail launch (DOTS_MG_TAIL_ROWS)
     int cg_graph_mg = -1;
+    int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
+    int zmid_stale = 0;           // z_mid does not belong to the current iterate
     FrontDev front{};             // multifrontal factor (n_nodes == 0: none)
     int use_front = 0;
     int front_fwd_ptr[66]{}, front_bwd_ptr[66]{};   // workgroup ranges of the tree levels in fwd_desc / bwd_desc

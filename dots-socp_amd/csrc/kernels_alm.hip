@@ -14,6 +14,11 @@ namespace dots {
 // norm, forms lambda, and walks it again to write z_mid of its own corners (no atomics: every
 // corner belongs to exactly one vertex).  beta_mid is read from HBM once, the second walk hits L2.
 // ------------------------------------------------------------------------------------------
+// ONLY_MULTIPLIER: the iteration driver (dots_step) does not need z_mid in memory: it stores the cone
+// multiplier lambda[v][t] (T*V values instead of 18*T*F) and steps 2+3 rebuild z_mid = lambda/D * pre-image on
+// the fly from beta_mid and B, which they read anyway: the second corner walk and 18*T*F stores disappear here,
+// 18*T*F loads disappear there.
+template <bool ONLY_MULTIPLIER>
 __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, double cd) {
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
@@ -45,6 +50,10 @@ __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, doub
         if (lam == lam) lam = fmin(fmax(lam, 0.0), 1.0);  // np.clip keeps NaN; fmin/fmax would drop it
         d.zf[iv] = (lam >= 1.0) ? w_fst : lam * nrm;
         d.ze[iv] = lam * w_end;
+        if (ONLY_MULTIPLIER) {
+            d.lamc[iv] = lam;
+            continue;
+        }
         for (int j = j0; j < j1; ++j) {
             const int fk = d.cidx[j];
             const int f = fk / 3;
@@ -61,9 +70,13 @@ __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, doub
     }
 }
 
-int launch_soc_projection(Ctx *c) {
-    hipLaunchKernelGGL(k_soc_projection, dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, c->prm.scale_z,
-                       c->prm.const_d);
+int launch_soc_projection(Ctx *c, int zmid_mode) {
+    if (zmid_mode)
+        hipLaunchKernelGGL((k_soc_projection<true>), dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, c->prm.scale_z,
+                           c->prm.const_d);
+    else
+        hipLaunchKernelGGL((k_soc_projection<false>), dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, c->prm.scale_z,
+                           c->prm.const_d);
     DOTS_HIP(hipGetLastError());
     return 0;
 }
@@ -158,6 +171,9 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_vertex(Dev d, double sz
     }
 }
 
+// ZMODE 0: z_mid is read from memory; 1: rebuilt from the cone multiplier (same expression as the projection
+// kernel: z = (lambda / D) * (D * (sz/sqrt3 * B_old - beta_mid))) and stored; 2: rebuilt, not stored.
+template <int ZMODE>
 __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double sz, double tau) {
     const int tile = xcd_tile(blockIdx.x, d.n_ftiles);
     if (tile >= d.n_ftiles) return;
@@ -173,22 +189,35 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
         for (int k = 0; k < 3; ++k) gx += d.hat[(f * 3 + k) * 3 + c] * d.phi[idxV(d, d.tri[f * 3 + k], t)];
         double z0[3], b0[3], z1[3], b1[3];
         double S = 0.0;
+        const int64_t ie = idxF(d, f, c, t);
+        const double sBold = ZMODE ? sB * d.B[ie] : 0.0;   // both pre-images of this thread's corners use B_old at ITS node
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             z0[k] = b0[k] = z1[k] = b1[k] = 0.0;
+            const double D = ZMODE ? d.fk_D[f * 3 + k] : 1.0;
+            const int ivk = ZMODE ? idxV(d, d.tri[f * 3 + k], t) : 0;
             if (t < d.T) {
                 const int64_t i = idxM(d, f * 3 + k, 0, c, t);
-                z0[k] = d.zm[i];
                 b0[k] = d.bm[i];
+                if (ZMODE) {
+                    z0[k] = (d.lamc[ivk] / D) * (D * (sBold - b0[k]));
+                    if (ZMODE == 1) d.zm[i] = z0[k];
+                } else {
+                    z0[k] = d.zm[i];
+                }
             }
             if (t > 0) {
                 const int64_t i = idxM(d, f * 3 + k, 1, c, t - 1);
-                z1[k] = d.zm[i];
                 b1[k] = d.bm[i];
+                if (ZMODE) {
+                    z1[k] = (d.lamc[ivk - 1] / D) * (D * (sBold - b1[k]));
+                    if (ZMODE == 1) d.zm[i] = z1[k];
+                } else {
+                    z1[k] = d.zm[i];
+                }
             }
             S += (z0[k] + b0[k]) + (z1[k] + b1[k]);
         }
-        const int64_t ie = idxF(d, f, c, t);
         const double Eo = d.E[ie];
         const double Bn = (gx + Eo + sB * S) / ((t == 0 || t == d.T) ? diag_bd : diag_in);
         d.B[ie] = Bn;
@@ -202,12 +231,14 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
     }
 }
 
-int launch_q_lambda_mult(Ctx *c) {
+int launch_q_lambda_mult(Ctx *c, int zmid_mode) {
     const dots_params &p = c->prm;
     hipLaunchKernelGGL(k_q_lambda_mult_vertex, dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, p.scale_z,
                        p.const_d, p.congestion * p.r, p.tau);
-    hipLaunchKernelGGL(k_q_lambda_mult_triangle, dim3(xcd_grid(c->d.n_ftiles)), dim3(BLOCK), 0, c->stream, c->d, p.scale_z,
-                       p.tau);
+    const dim3 gf(xcd_grid(c->d.n_ftiles));
+    if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_triangle<2>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau);
+    else if (zmid_mode == 1) hipLaunchKernelGGL((k_q_lambda_mult_triangle<1>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau);
+    else hipLaunchKernelGGL((k_q_lambda_mult_triangle<0>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau);
     DOTS_HIP(hipGetLastError());
     return 0;
 }

@@ -671,7 +671,7 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
         if (!direct) hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.phi, g.cg_x, 0);
         b = g.cg_p0;
         const double mean_scale = (singular && owns_mode0) ? 1.0 / d.V : 0.0;
-        hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, owns_mode0 ? gs : 0, g.cg_ncol, mean_scale);
+        if (!direct) hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, owns_mode0 ? gs : 0, g.cg_ncol, mean_scale);
     } else {
         if (MODAL) {
             // b^ = Q^T b (into p0 as scratch), x^ = Q^T phi (warm start in mode space)
@@ -680,7 +680,7 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
             b = d.cg_p0;   // consumed by k_cg_r0 before iteration 0 (which reads no p_old: beta = 0) writes p1
         }
         const double mean_scale = !singular ? 0.0 : (MODAL ? 1.0 / d.V : 1.0 / ((double)d.V * (d.T + 1)));
-        hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, gt, MODAL ? d.cg_ncol : 1, mean_scale);
+        if (!direct) hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, gt, MODAL ? d.cg_ncol : 1, mean_scale);
     }
     DOTS_HIP(hipGetLastError());
     int rc;

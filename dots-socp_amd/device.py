@@ -121,10 +121,17 @@ class DeviceProblem:
         return {n: self.download(n) for n in STATE_NAMES}
 
     # ---- the hot loop
-    def step(self, n_iters=1):
+    def step(self, n_iters=1, wait=True):
+        """``wait=False``: only enqueue (direct solver); returns None, nothing is timed."""
+        if not wait:
+            _lib.check(self.lib.dots_step(self._h, int(n_iters), None), "dots_step")
+            return None
         st = _lib.StepStats()
         _lib.check(self.lib.dots_step(self._h, int(n_iters), C.byref(st)), "dots_step")
         return st
+
+    def step_flags(self, skip_z_mid=False):
+        _lib.check(self.lib.dots_step_flags(self._h, 1 if skip_z_mid else 0), "dots_step_flags")
 
     # ---- sharded iteration (multi-GPU): begin -> all-gather by the caller -> end
     def shard_elems(self):

@@ -144,7 +144,8 @@ class ShardedAlmSolver(AlmSolver):
         self._recv = torch.zeros(elems * comm.size, dtype=torch.float64, device=dev)
         self.comm_seconds = 0.0
 
-    def _device_step(self):
+    def _device_step(self, quiet=False):
+        self.dev.step_flags(skip_z_mid=quiet)
         st1 = self.dev.step_begin(self._send.data_ptr(), self._send.numel())
         t0 = time.perf_counter()
         self.comm.all_gather(self._recv, self._send)

@@ -71,7 +71,8 @@ class AlmSolver:
         self.n_time, self.nit, self.tol, self.time_limit = int(n_time), int(nit), tol, time_limit
         self.is_z_scaling, self.is_constant_scaling = is_z_scaling, is_constant_scaling
         self.check_kkt_step_by_step = check_kkt_step_by_step
-        direct = lap_solver == "modal_direct"
+        self.direct = direct = lap_solver == "modal_direct"
+        self.untimed_steps = 0
         if direct and reorder is True:
             reorder = "nd"      # the elimination order of the factor doubles as the locality numbering
         self.dev = dev = DeviceProblem(n_time, geometry, lap_solver="modal_pcg" if direct else lap_solver, device=device,
@@ -224,9 +225,17 @@ class AlmSolver:
             return (self.r * self.dual_scale) * arr
         return (self.r * self.scale_z * self.dual_scale) * arr
 
-    def _device_step(self):
-        """Steps 1-3 on the device; the multi-GPU solver overrides this with begin / all-gather / end."""
-        self._account(self.dev.step(1))
+    def _device_step(self, quiet=False):
+        """Steps 1-3 on the device; the multi-GPU solver overrides this with begin / all-gather / end.
+
+        ``quiet``: nothing is read back after this iteration (no KKT evaluation, not the last one): z_mid
+        need not be stored, and with the direct solver the host does not wait for the device either."""
+        self.dev.step_flags(skip_z_mid=quiet)
+        if quiet and self.direct:
+            self.dev.step(1, wait=False)
+            self.untimed_steps += 1
+        else:
+            self._account(self.dev.step(1))
 
     def _time_is_up(self):
         return (time.perf_counter() - self.start_time) > self.time_limit
@@ -252,9 +261,15 @@ class AlmSolver:
             if rescale_z > 1.25:
                 self.scale_variable_z(rescale_z, msg=f"Rescale z at iteration {it}")
 
-        self._device_step()                                                     # steps 1-3 (:674-722)
-
+        # The reference looks at the clock after the step (:727); here before it, so that it is known in
+        # advance whether this iteration's results are read back (a wall-clock limit has no parity to keep).
         is_time_used_up = self._time_is_up()
+        validator = self.kkt_validator
+        quiet = not (is_time_used_up or self.check_kkt_step_by_step or it + 1 >= self.nit or params.peek_adjust(it)
+                     or validator.will_validate_next()
+                     or (self.is_constant_scaling and params.is_to_scale(it + 1)))   # the next iteration opens with norms of z
+        self._device_step(quiet)                                                # steps 1-3 (:674-722)
+
         adjust = params.is_to_adjust(it) or is_time_used_up
         required = KKT_PRIM + KKT_DUAL if adjust else None
         validator = self.kkt_validator

@@ -150,8 +150,19 @@ int dots_download(dots_ctx *ctx, int array_id, double *host, int64_t count);
 int64_t dots_array_count(dots_ctx *ctx, int array_id);
 
 /* ---- the hot loop ------------------------------------------------------------------------ */
-/* n ALM iterations, steps 1-3 of solver_socp.py:674-722 (is_palm = False), device resident. */
+/* n ALM iterations, steps 1-3 of solver_socp.py:674-722 (is_palm = False), device resident.
+ * stats == NULL: the iterations are only enqueued on the context's stream (no host wait, nothing timed;
+ * meant for the direct solver, which needs no host round trip) -- any later call that returns data waits. */
 int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
+
+/* Flags for the following dots_step / dots_step_end calls.
+ * DOTS_STEP_SKIP_Z_MID: z_mid (18*T*F values, an intermediate between the cone projection and steps 2+3) is
+ * rebuilt on the fly and not stored: the iterate is the same bit for bit, but z_mid in memory is unspecified
+ * afterwards.  dots_kkt(PRIM_Z) and dots_download(Z_MID) then fail with DOTS_ERR_STATE until a step without the
+ * flag (or an upload / the projection phase) has produced it again.  The host driver sets it on the iterations
+ * after which neither KKT residuals nor the solution are read (solver_socp.py's lazy validator, :766-788). */
+#define DOTS_STEP_SKIP_Z_MID 1u
+int dots_step_flags(dots_ctx *ctx, uint32_t flags);
 
 /* One ALM iteration split around the only exchange of the multi-GPU path (mode-sharded solve):
  *   dots_step_begin  right-hand side + PCG for this context's time modes; the mode-space solution

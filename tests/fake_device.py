@@ -66,6 +66,9 @@ class FakeDeviceProblem:
         s.bnd[0] = -p.boundary_scale * self.mu0 / (p.r * s.h)
         s.bnd[-1] = p.boundary_scale * self.mu1 / (p.r * s.h)
 
+    def step_flags(self, skip_z_mid=False):
+        pass
+
     def setup_frontal(self, **kw):
         return {"levels": 1}
 

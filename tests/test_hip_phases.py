@@ -233,3 +233,38 @@ def test_full_iterations_track_oracle():
         for i in range(7):
             assert abs(got[i][0] - want[i]) <= 1e-7 * abs(want[i]) + 1e-14, (lap, i)
         dev.close()
+
+
+def test_lazy_z_mid_steps_are_bit_identical():
+    """Iterations that rebuild z_mid on the fly (DOTS_STEP_SKIP_Z_MID, enqueued without waiting) give the same
+    iterate bit for bit as stored-z_mid iterations; reading z_mid while it is stale fails loudly."""
+    from dots_socp_amd._lib import HipLibraryError
+    from dots_socp_amd.device import DeviceProblem
+
+    g = golden("ops_ico1.npz")
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    T = int(g["n_time"])
+    out = []
+    for lazy in (False, True):
+        dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+        dev.setup_frontal(leaf=4)
+        dev.scale_z(2.0, 0.5, 2.0)
+        dev.set_params(scale_z=2.0, const_d=2.0, congestion=0.05)
+        if lazy:
+            dev.step_flags(skip_z_mid=True)
+            for _ in range(11):
+                dev.step(1, wait=False)
+            with pytest.raises(HipLibraryError):
+                dev.kkt([1])
+            with pytest.raises(HipLibraryError):
+                dev.download("z_mid")
+            assert dev.kkt([0, 2, 3])[0][0] > 0          # conditions that do not read z_mid still work
+            dev.step_flags(skip_z_mid=False)
+            dev.step(1)
+        else:
+            dev.step(12)
+        out.append((dev.download_all(), dev.kkt(range(7))))
+        dev.close()
+    for k in out[0][0]:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k
+    assert out[0][1] == out[1][1]
