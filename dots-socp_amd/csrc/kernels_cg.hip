@@ -425,6 +425,49 @@ __global__ __launch_bounds__(BLOCK) void k_time_modes(Dev d, const double *__res
     }
 }
 
+// The same transform with Q and the tile of x staged in LDS (T + 1 <= 64): every x row and every Q entry is
+// read from memory once per workgroup instead of once per output; a thread computes four outputs that share
+// their Q column.  x rows are padded by one double so that the rows a wavefront broadcasts sit in different banks.
+template <bool FWD>
+__global__ __launch_bounds__(BLOCK) void k_time_modes_tile(Dev d, const double *__restrict__ x, double *__restrict__ y) {
+    extern __shared__ double tm_lds[];
+    const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+    double *Qs = tm_lds;                 // [n][TP]   Qs[i][j] = coefficient of x[.][i] in y[.][j]
+    double *xs = tm_lds + n * TP;        // [VT][TPp]
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    if (tile >= d.n_vtiles) return;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * TP; e += BLOCK) {
+        const int i = e >> d.tp_shift, j = e & (TP - 1);
+        Qs[e] = j < n ? (FWD ? d.Q[i * n + j] : d.Q[j * n + i]) : 0.0;
+    }
+    const int v0 = tile * d.VT;
+    for (int e = tid; e < TILE_ELEMS; e += BLOCK) {
+        const int vl = e >> d.tp_shift, t = e & (TP - 1);
+        xs[vl * TPp + t] = (v0 + vl < d.V && t < n) ? x[idxV(d, v0 + vl, t)] : 0.0;
+    }
+    __syncthreads();
+    const int j = tid & (TP - 1), g = tid >> d.tp_shift, G = BLOCK >> d.tp_shift;   // G row groups; a thread takes rows g, g+G, ...
+    if (j >= n) return;
+    for (int vl0 = g; vl0 < d.VT; vl0 += 4 * G) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        const double *x0 = xs + vl0 * TPp;
+        for (int i = 0; i < n; ++i) {
+            const double q = Qs[(i << d.tp_shift) + j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (vl0 + r * G < d.VT) acc[r] += q * x0[r * G * TPp + i];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = v0 + vl0 + r * G;
+            if (vl0 + r * G < d.VT && v < d.V) y[idxV(d, v, j)] = acc[r];
+        }
+    }
+}
+static size_t time_modes_tile_lds(const Dev &d) { return sizeof(double) * ((size_t)(d.T + 1) * d.TP + (size_t)d.VT * (d.TP + 1)); }
+static bool time_modes_tile_ok(const Dev &d) { return d.T + 1 <= 64 && d.TP <= BLOCK && d.VT >= 1; }
+
 // ------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------
@@ -675,7 +718,10 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
     } else {
         if (MODAL) {
             // b^ = Q^T b (into p0 as scratch), x^ = Q^T phi (warm start in mode space)
-            hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_b, d.cg_p0, 1);
+            if (direct && time_modes_tile_ok(d))
+                hipLaunchKernelGGL((k_time_modes_tile<true>), dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, d.cg_b, d.cg_p0);
+            else
+                hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_b, d.cg_p0, 1);
             if (!direct) hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.phi, d.cg_x, 0);
             b = d.cg_p0;   // consumed by k_cg_r0 before iteration 0 (which reads no p_old: beta = 0) writes p1
         }
@@ -694,7 +740,10 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
     }
     if (rc) return rc;
     if (MODAL && !sharded) {
-        hipLaunchKernelGGL((k_time_modes<false>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_x, d.phi, 0);
+        if (time_modes_tile_ok(d))
+            hipLaunchKernelGGL((k_time_modes_tile<false>), dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, d.cg_x, d.phi);
+        else
+            hipLaunchKernelGGL((k_time_modes<false>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_x, d.phi, 0);
         DOTS_HIP(hipGetLastError());
     }
     return 0;
