@@ -197,6 +197,16 @@ def main():
             "ms_per_cycle": ms_vc, "finest_level_algorithmic_bytes": bytes_vc,
             "achieved_finest_only": bytes_vc / (ms_vc * 1e-3) / 1e9, "hierarchy": alm.mg_summary,
         }
+    # one streaming launch of known size: calibrates the FETCH_SIZE / WRITE_SIZE counters when this command runs
+    # under rocprofv3 --pmc (profiles/tools/pmc_summary.py); a single launch, outside the timed region
+    _, calib_bytes = alm.dev.bench_kernel(which=4, reps=1)
+    roofline["pmc_calibration_bytes_each_way"] = calib_bytes
+    traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    if world == 1 and args.lap_solver == "modal_direct" and os.path.exists(traffic_file):
+        with open(traffic_file) as fh:
+            tr = json.load(fh)
+        roofline["traffic"] = tr["bytes_per_solve"]
+        roofline["traffic_source"] = tr["source"]
     dev_bytes = alm.dev.device_bytes()
     alm.close()
 

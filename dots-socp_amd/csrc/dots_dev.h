@@ -147,6 +147,7 @@ int launch_scale_array(Ctx *c, int array_id, double factor);
 int launch_to_device_layout(Ctx *c, int array_id, const double *staged);
 int launch_from_device_layout(Ctx *c, int array_id, double *staged);
 int launch_operator(Ctx *c, int op, double scale, const double *in_staged, double *out_staged);
+int launch_calibration(Ctx *c, double *bytes_each_way);
 int cg_solve(Ctx *c, dots_step_stats *stats);
 int cg_apply_operator(Ctx *c, const double *x_node, double *y_node);  // y = K x in node layout
 int cg_finish_sharded(Ctx *c, const double *gathered);                // phi from all ranks' mode-space solutions
@@ -195,6 +196,7 @@ struct Ctx {
     int front_fwd_ptr[66]{}, front_bwd_ptr[66]{};   // workgroup ranges of the tree levels in fwd_desc / bwd_desc
     int front_fwd_rb[65]{}, front_bwd_cb[65]{};     // rows / columns per workgroup on each level
     int front_fwd_nb[65]{}, front_bwd_nb[65]{};     // threads per workgroup on each level (256, or 1024 where a level has few rows)
+    int front_rb_max = 4;         // most rows (columns) of a node per workgroup (DOTS_FRONT_RB: 1..16, for A/B measurements)
     double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps)
     void *front_allocs[24]{};
     int n_front_allocs = 0;

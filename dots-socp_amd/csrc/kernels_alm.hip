@@ -253,6 +253,21 @@ __global__ __launch_bounds__(BLOCK) void k_divide(double *x, int64_t n, double f
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) x[i] /= f;
 }
 
+// Calibration launch for the PMC traffic counters (profiles/tools/pmc_summary.py): exactly one 8-byte load and
+// one 8-byte store per element of the staging buffer, the access width of every kernel of this library.
+__global__ __launch_bounds__(BLOCK) void k_calib_stream(double *x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) x[i] = 2.0 * x[i];
+}
+int launch_calibration(Ctx *c, double *bytes_each_way) {
+    const int64_t n = c->stage_count;
+    hipLaunchKernelGGL(k_calib_stream, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, c->stage, n);
+    DOTS_HIP(hipGetLastError());
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    *bytes_each_way = 8.0 * (double)n;
+    return 0;
+}
+
 static int grid_for(int64_t n) {
     int64_t g = (n + BLOCK - 1) / BLOCK;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));

@@ -779,6 +779,10 @@ int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes) {
     const Dev &d = modal ? c->dcg : c->d;
     CgArgs a = make_args(c, modal);
     const size_t lds = cg_lds_bytes(a.cap, a.vt, a.nb);
+    if (which == 4) {   // one streaming launch of known size (calibrates the PMC traffic counters)
+        *ms = 0.0;
+        return launch_calibration(c, bytes);
+    }
     if (which == 3) {   // both sweeps of the direct solve on whatever the vectors hold
         if (!modal || c->front.n_nodes == 0) {
             set_error("bench: no multifrontal factor on this context");

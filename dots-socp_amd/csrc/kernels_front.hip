@@ -25,19 +25,55 @@
 
 namespace dots {
 
-constexpr int FRONT_RB = 4;    // most rows (columns) of a node one workgroup handles
-
 struct FrontArgs {
     int sh, TP, ncol;          // mode pitch (log2, value) and live modes
 };
 
 __device__ __forceinline__ int64_t front_row(const FrontDev &f, int k) { return f.vmap ? f.vmap[k] : k; }
 
-// forward sweep of one tree height.  Workgroup = (node, rb rows); thread = (mode a, part q of the dot product).
+// Sum `acc` over the threads of the workgroup that share a mode (the parts q of the dot products): lanes of a
+// wavefront first (xor-shuffles), then one LDS slot per (row, wavefront, mode).  Returns nothing; the caller reads
+// red[(r * NW + w) * TP + a] for w < NW after the barrier.  TP <= 64: a wavefront holds 64 / TP parts.
+template <int NB, int RB>
+__device__ __forceinline__ void front_fold(double (&acc)[RB], double *red, int TP, int a, int tid) {
+    constexpr int NW = NB / 64;
+    if (TP <= 64) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            double s = acc[r];
+            for (int o = 32; o >= TP; o >>= 1) s += __shfl_xor(s, o, 64);
+            acc[r] = s;
+        }
+        if ((tid & 63) < TP) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) red[(r * NW + (tid >> 6)) * TP + a] = acc[r];
+        }
+    } else {      // TP = 128 / 256: a wavefront covers part of one row of modes; one slot per thread
+#pragma unroll
+        for (int r = 0; r < RB; ++r) red[r * NB + tid] = acc[r];
+    }
+    __syncthreads();
+}
 template <int NB>
+__device__ __forceinline__ double front_folded(const double *red, int r, int TP, int sh, int a) {
+    constexpr int NW = NB / 64;
+    double s = 0.0;
+    if (TP <= 64) {
+        for (int w = 0; w < NW; ++w) s += red[(r * NW + w) * TP + a];
+    } else {
+        for (int k = 0; k < (NB >> sh); ++k) s += red[r * NB + (k << sh) + a];
+    }
+    return s;
+}
+
+// forward sweep of one tree height.  Workgroup = (node, rb <= RB rows); thread = (mode a, part q of the dot product).
+// Every load of the loop body is unconditional (rows past the block are clamped to its first row and their sums
+// dropped; leaves read their "children's" planes from the zero pad at the start of W; the upper triangle of L^-1
+// is stored as zeros), so that the compiler issues the RB + 3 loads of a step back to back and waits once.
+template <int NB, int RB, bool VMAP>
 __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const int2 *__restrict__ desc, int rb, const double *__restrict__ bhat,
                                                   double *__restrict__ Y) {
-    __shared__ double red[FRONT_RB * NB];
+    __shared__ double red[RB * (NB / 64) * 64];
     const int2 ds = desc[blockIdx.x];
     const FrontNode nd = f.nodes[ds.x];
     const int row0 = ds.y;
@@ -50,42 +86,48 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
     const bool live = a < g.ncol;
     const int nr = min(rb, m - row0);
 
-    double acc[FRONT_RB] = {0.0, 0.0, 0.0, 0.0};
+    double acc[RB];
+    const double *rowp[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        acc[r] = 0.0;
+        rowp[r] = Fp + (((int64_t)(r < nr ? row0 + r : row0) * n) << sh);
+    }
     // rows of L^-1 only need the columns j <= i: the block's last row bounds the loop
     const int last = row0 + nr - 1;
     const int jmax = last < n ? last + 1 : n;
     if (live) {
         for (int j = q; j < jmax; j += Q) {
-            double w = bhat[(front_row(f, nd.k0 + j) << sh) + a];
-            if (nd.has_children) w -= W0[(int64_t)j << sh] + W0[plane + ((int64_t)j << sh)];
+            const int64_t jo = (int64_t)j << sh;
+            const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
+            const double wb = bhat[(row << sh) + a];
+            const double w0 = W0[jo], w1 = W0[plane + jo];
+            double fv[RB];
 #pragma unroll
-            for (int r = 0; r < FRONT_RB; ++r) {
-                const int i = row0 + r;
-                if (r < nr && (i >= n || j <= i)) acc[r] += Fp[((int64_t)i * n + j) << sh] * w;
-            }
+            for (int r = 0; r < RB; ++r) fv[r] = rowp[r][jo];
+            const double w = wb - (w0 + w1);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] += fv[r] * w;
         }
     }
-#pragma unroll
-    for (int r = 0; r < FRONT_RB; ++r) red[r * NB + tid] = acc[r];
-    __syncthreads();
+    front_fold<NB, RB>(acc, red, g.TP, a, tid);
     for (int r = q; r < nr && live; r += Q) {
-        double s = 0.0;
-        for (int k = 0; k < Q; ++k) s += red[r * NB + (k << sh) + a];
+        double s = front_folded<NB>(red, r, g.TP, sh, a);
         const int i = row0 + r;
         if (i < n) {
             Y[(front_row(f, nd.k0 + i) << sh) + a] = s;
         } else {   // update row: carry the children's contributions on, hand the sum to the parent's plane
-            if (nd.has_children) s += W0[(int64_t)i << sh] + W0[plane + ((int64_t)i << sh)];
+            s += W0[(int64_t)i << sh] + W0[plane + ((int64_t)i << sh)];
             f.W[((nd.parent_w + f.cmap[nd.bdoff + (i - n)]) << sh) + a] = s;
         }
     }
 }
 
-// backward sweep of one tree height.  Workgroup = (node, cb columns).
-template <int NB>
+// backward sweep of one tree height.  Workgroup = (node, cb <= RB columns).  Same load discipline.
+template <int NB, int RB, bool VMAP>
 __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const int2 *__restrict__ desc, int cb, const double *__restrict__ Y,
                                                   double *X) {
-    __shared__ double red[FRONT_RB * NB];
+    __shared__ double red[RB * (NB / 64) * 64];
     const int2 ds = desc[blockIdx.x];
     const FrontNode nd = f.nodes[ds.x];
     const int col0 = ds.y;
@@ -97,26 +139,39 @@ __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const
     const bool live = a < g.ncol;
     const int nc = min(cb, n - col0);
 
-    double acc[FRONT_RB] = {0.0, 0.0, 0.0, 0.0};
-    if (live) {
-        // column i of L^-1 is zero above the diagonal: start at the block's first column
-        for (int j = col0 + q; j < m; j += Q) {
-            // X of boundary rows: written by the launches of greater heights
-            const double v = j < n ? Y[(front_row(f, nd.k0 + j) << sh) + a] : -X[((int64_t)bdv[j - n] << sh) + a];
-            const double *__restrict__ row = Fp + (((int64_t)j * n + col0) << sh);
+    double acc[RB];
+    int64_t co[RB];      // column offsets (columns past the block: its first column, sums dropped)
 #pragma unroll
-            for (int r = 0; r < FRONT_RB; ++r)
-                if (r < nc && j >= col0 + r) acc[r] += row[(int64_t)r << sh] * v;
+    for (int r = 0; r < RB; ++r) {
+        acc[r] = 0.0;
+        co[r] = (int64_t)(r < nc ? col0 + r : col0) << sh;
+    }
+    if (live) {
+        // rows of the separator: y_p.  Column i of L^-1 is zero above the diagonal: start at the block's first column
+        for (int j = col0 + q; j < n; j += Q) {
+            const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
+            const double v = Y[(row << sh) + a];
+            const double *__restrict__ Fj = Fp + (((int64_t)j * n) << sh);
+            double fv[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) fv[r] = Fj[co[r]];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] += fv[r] * v;
+        }
+        // boundary rows: -x of the ancestors (written by the launches of greater heights)
+        for (int j = n + q; j < m; j += Q) {
+            const double v = X[((int64_t)bdv[j - n] << sh) + a];
+            const double *__restrict__ Fj = Fp + (((int64_t)j * n) << sh);
+            double fv[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) fv[r] = Fj[co[r]];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] -= fv[r] * v;
         }
     }
-#pragma unroll
-    for (int r = 0; r < FRONT_RB; ++r) red[r * NB + tid] = acc[r];
-    __syncthreads();
-    for (int r = q; r < nc && live; r += Q) {
-        double s = 0.0;
-        for (int k = 0; k < Q; ++k) s += red[r * NB + (k << sh) + a];
-        X[(front_row(f, nd.k0 + col0 + r) << sh) + a] = s;
-    }
+    front_fold<NB, RB>(acc, red, g.TP, a, tid);
+    for (int r = q; r < nc && live; r += Q)
+        X[(front_row(f, nd.k0 + col0 + r) << sh) + a] = front_folded<NB>(red, r, g.TP, sh, a);
 }
 
 void front_release(Ctx *c) {
@@ -205,7 +260,11 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     std::vector<FrontNode> nodes((size_t)nn);
     std::vector<int> vmap((size_t)d.V), bd_vertex((size_t)std::max<int64_t>(h->update_rows, 1)), cmap((size_t)std::max<int64_t>(h->update_rows, 1), 0);
     std::vector<char> seen((size_t)d.V, 0);
-    int64_t wrows = 0;
+    // W starts with a pad of zeros as long as the two planes of the largest front: nodes without children read their
+    // (absent) children's updates there, so the sweeps need no branch on "has children"
+    int max_front = 1;
+    for (int p = 0; p < nn; ++p) max_front = std::max(max_front, h->node_n[p] + h->node_b[p]);
+    int64_t wrows = 2 * (int64_t)max_front;
     {
         int k0 = 0;
         int64_t soff = 0;
@@ -277,7 +336,14 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             rows += h->node_n[p] + h->node_b[p];
             cols += h->node_n[p];
         }
-        auto block = [](int64_t total) { return total >= 4096 ? 4 : (total >= 2048 ? 2 : 1); };   // keep >= ~1000 workgroups where the level allows
+        // keep >= ~1000 workgroups where the level allows; at the bottom of the tree (tens of thousands of rows in
+        // small nodes) up to 16 rows per workgroup: the fixed latency chain of a workgroup (descriptor, node
+        // record, loads, fold, store) then covers 4x more bytes
+        const int rbmax = c->front_rb_max;
+        auto block = [rbmax](int64_t total) {
+            int b = total >= 16384 ? 16 : (total >= 8192 ? 8 : (total >= 4096 ? 4 : (total >= 2048 ? 2 : 1)));
+            return std::min(b, rbmax);
+        };
         const int rb = block(rows), cb = block(cols);
         c->front_fwd_rb[l] = rb;
         c->front_bwd_cb[l] = cb;
@@ -328,22 +394,33 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
     const FrontDev &f = c->front;
     if (f.n_nodes == 0) { set_error("front_solve: no factor installed"); return DOTS_ERR_STATE; }
     const FrontArgs g{d.tp_shift, d.TP, d.cg_ncol};
+    const bool vm = f.vmap != nullptr;
+#define FRONT_LAUNCH(K, NBV, RBV, ptr, blk, ...)                                                                                   \
+    do {                                                                                                                           \
+        if (vm) hipLaunchKernelGGL((K<NBV, RBV, true>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, __VA_ARGS__);            \
+        else hipLaunchKernelGGL((K<NBV, RBV, false>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, __VA_ARGS__);              \
+    } while (0)
     for (int l = 0; l < f.n_levels; ++l) {
         const int n = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
         if (n <= 0) continue;
-        if (c->front_fwd_nb[l] == 1024)
-            hipLaunchKernelGGL((k_front_fwd<1024>), dim3(n), dim3(1024), 0, c->stream, g, f, f.fwd_desc + c->front_fwd_ptr[l], c->front_fwd_rb[l], bhat, y);
-        else
-            hipLaunchKernelGGL((k_front_fwd<256>), dim3(n), dim3(256), 0, c->stream, g, f, f.fwd_desc + c->front_fwd_ptr[l], c->front_fwd_rb[l], bhat, y);
+        const int2 *ptr = f.fwd_desc + c->front_fwd_ptr[l];
+        const int blk = c->front_fwd_rb[l];
+        if (c->front_fwd_nb[l] == 1024) FRONT_LAUNCH(k_front_fwd, 1024, 4, ptr, blk, bhat, y);
+        else if (blk > 8) FRONT_LAUNCH(k_front_fwd, 256, 16, ptr, blk, bhat, y);
+        else if (blk > 4) FRONT_LAUNCH(k_front_fwd, 256, 8, ptr, blk, bhat, y);
+        else FRONT_LAUNCH(k_front_fwd, 256, 4, ptr, blk, bhat, y);
     }
     for (int l = f.n_levels - 1; l >= 0; --l) {
         const int n = c->front_bwd_ptr[l + 1] - c->front_bwd_ptr[l];
         if (n <= 0) continue;
-        if (c->front_bwd_nb[l] == 1024)
-            hipLaunchKernelGGL((k_front_bwd<1024>), dim3(n), dim3(1024), 0, c->stream, g, f, f.bwd_desc + c->front_bwd_ptr[l], c->front_bwd_cb[l], y, x);
-        else
-            hipLaunchKernelGGL((k_front_bwd<256>), dim3(n), dim3(256), 0, c->stream, g, f, f.bwd_desc + c->front_bwd_ptr[l], c->front_bwd_cb[l], y, x);
+        const int2 *ptr = f.bwd_desc + c->front_bwd_ptr[l];
+        const int blk = c->front_bwd_cb[l];
+        if (c->front_bwd_nb[l] == 1024) FRONT_LAUNCH(k_front_bwd, 1024, 4, ptr, blk, y, x);
+        else if (blk > 8) FRONT_LAUNCH(k_front_bwd, 256, 16, ptr, blk, y, x);
+        else if (blk > 4) FRONT_LAUNCH(k_front_bwd, 256, 8, ptr, blk, y, x);
+        else FRONT_LAUNCH(k_front_bwd, 256, 4, ptr, blk, y, x);
     }
+#undef FRONT_LAUNCH
     DOTS_HIP(hipGetLastError());
     return 0;
 }

@@ -307,7 +307,9 @@ int dots_front_pitch(dots_ctx *ctx);
 /* Launch the dominant kernel (the PCG operator application) `reps` times on the context's stream
  * between two hipEvents and return the average milliseconds per launch and the algorithmic bytes
  * one launch moves (DESIGN.md section "roofline"). */
-/* which: 0 PCG operator application, 1 PCG vector update, 2 one multigrid V-cycle, 3 both sweeps of the direct solve */
+/* which: 0 PCG operator application, 1 PCG vector update, 2 one multigrid V-cycle, 3 both sweeps of the direct
+ * solve, 4 one calibration launch (k_calib_stream: reads and writes *bytes_per_launch bytes each, 8 B per lane)
+ * for the PMC traffic counters */
 int dots_bench_kernel(dots_ctx *ctx, int which, int reps, double *ms_per_launch, double *bytes_per_launch);
 
 /* device memory in use by the context, bytes */
