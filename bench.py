@@ -197,6 +197,20 @@ def main():
             "ms_per_cycle": ms_vc, "finest_level_algorithmic_bytes": bytes_vc,
             "achieved_finest_only": bytes_vc / (ms_vc * 1e-3) / 1e9, "hierarchy": alm.mg_summary,
         }
+    # SURVEY.md section 8(d)'s per-iteration figure: 2 S (every state array read and written once) + the right-hand
+    # side + the solve, over the measured step time
+    S_bytes = 8 * ((n_time + 1) * V + 7 * n_time * V + 6 * (n_time + 1) * F + 36 * n_time * F)
+    rhs_bytes = 8 * (3 * n_time * V + 6 * (n_time + 1) * F + 2 * (n_time + 1) * V)
+    if "algorithmic_bytes_per_solve" in roofline:
+        solve_bytes = roofline["algorithmic_bytes_per_solve"]
+    else:
+        solve_bytes = cg_per_it * (roofline["algorithmic_bytes_per_launch"] + roofline["second_kernel"]["algorithmic_bytes_per_launch"])
+    it_bytes = 2 * S_bytes + rhs_bytes + solve_bytes
+    roofline["whole_iteration"] = {
+        "algorithmic_bytes": it_bytes, "achieved": it_bytes / (elapsed / args.steps) / 1e9, "unit": "GB/s",
+        "frac": it_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+        "note": "2*S + rhs + solve bytes over the measured step (SURVEY.md 8d); the driver moves less than 2*S on iterations that do not store z_mid",
+    }
     # one streaming launch of known size: calibrates the FETCH_SIZE / WRITE_SIZE counters when this command runs
     # under rocprofv3 --pmc (profiles/tools/pmc_summary.py); a single launch, outside the timed region
     _, calib_bytes = alm.dev.bench_kernel(which=4, reps=1)
