@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--preconditioner", default="multigrid", choices=["multigrid", "jacobi"])
     ap.add_argument("--cg-tol", type=float, default=None)
     ap.add_argument("--mg-coarsest", type=int, default=None, help="rows of the dense coarsest multigrid level (default: solver default)")
+    ap.add_argument("--nd-leaf", type=int, default=None, help="leaf size of the nested dissection (default: solver default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-tol", action="store_true")
     ap.add_argument("--no-reorder", action="store_true", help="keep the generator's vertex numbering (A/B of the RCM renumbering)")
@@ -120,6 +121,8 @@ def main():
     n_time, congestion, tol = wl["n_time"], wl["congestion"], wl["tol"]
     cg_tol = args.cg_tol if args.cg_tol is not None else DEFAULT_CG_TOL
     mg_kw = {} if args.mg_coarsest is None else {"mg_coarsest": args.mg_coarsest}
+    if args.nd_leaf is not None:
+        mg_kw["nd_leaf"] = args.nd_leaf
     V, F = geom["vertices"].shape[0], geom["triangles"].shape[0]
 
     dist = None

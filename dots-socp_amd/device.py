@@ -22,11 +22,11 @@ def _ptr(a, ctype):
 
 class DeviceProblem:
     def __init__(self, n_time, geometry, lap_solver="spacetime_pcg", device=0, reorder=True, plan: DevicePlan | None = None,
-                 mode_shard=None):
+                 mode_shard=None, nd_leaf=16):
         """``mode_shard = (rank, n_ranks)``: this context solves only its slice of the T+1 time modes
         (multi-GPU, see distributed.py); the caller then drives ``step_begin`` / ``step_end``."""
         self.lib = _lib.load()
-        self.plan = plan if plan is not None else build_plan(n_time, geometry, reorder=reorder)
+        self.plan = plan if plan is not None else build_plan(n_time, geometry, reorder=reorder, nd_leaf=nd_leaf)
         p = self.plan
         self.T, self.V, self.F = p.n_time, p.n_vertices, p.n_triangles
         if lap_solver not in _lib.LAP_SOLVERS:

@@ -65,7 +65,7 @@ class AlmSolver:
     def __init__(self, n_time, geometry, congestion=0.0, nit=1000, eps=0.0, tol=1e-4, tau=1.90, is_z_scaling=True,
                  is_constant_scaling=False, check_kkt_step_by_step=False, init_solution=None, tol_checkpoints=None,
                  time_limit=1000, lap_solver="modal_direct", cg_tol=DEFAULT_CG_TOL, cg_max_iter=20000, device=0, reorder=True,
-                 preconditioner="multigrid", mg_coarsest=256, mode_shard=None):
+                 preconditioner="multigrid", mg_coarsest=256, mode_shard=None, nd_leaf=16):
         self.tol_checkpoints = _validate_checkpoints(tol_checkpoints, tol)
         self.checkpoint_solutions = []
         self.n_time, self.nit, self.tol, self.time_limit = int(n_time), int(nit), tol, time_limit
@@ -76,7 +76,7 @@ class AlmSolver:
         if direct and reorder is True:
             reorder = "nd"      # the elimination order of the factor doubles as the locality numbering
         self.dev = dev = DeviceProblem(n_time, geometry, lap_solver="modal_pcg" if direct else lap_solver, device=device,
-                                       reorder=reorder, mode_shard=mode_shard)
+                                       reorder=reorder, mode_shard=mode_shard, nd_leaf=nd_leaf)
 
         p = dev.params
         self.r = 1.0
@@ -366,6 +366,7 @@ def solver_socp(
         reorder=True,
         preconditioner="multigrid",
         mg_coarsest=256,
+        nd_leaf=16,
 ):
     """SOCP for dynamical optimal transport on a discrete surface, on the GPU.
 
@@ -380,7 +381,7 @@ def solver_socp(
                     is_constant_scaling=is_constant_scaling, check_kkt_step_by_step=check_kkt_step_by_step,
                     init_solution=init_solution, tol_checkpoints=tol_checkpoints, time_limit=time_limit,
                     lap_solver=lap_solver, cg_tol=cg_tol, cg_max_iter=cg_max_iter, device=device, reorder=reorder,
-                    preconditioner=preconditioner, mg_coarsest=mg_coarsest)
+                    preconditioner=preconditioner, mg_coarsest=mg_coarsest, nd_leaf=nd_leaf)
     try:
         for _ in range(nit):
             if alm.iterate():
