@@ -217,6 +217,14 @@ struct Ctx {
     }
 };
 
+// T + 1 <= 64: the time-mode transforms stage Q and a tile of rows in LDS (k_time_modes_tile, k_rhs_modes)
+inline bool time_modes_tile_ok(const Dev &d) { return d.T + 1 <= 64 && d.TP <= BLOCK && d.VT >= 1; }
+inline size_t time_modes_tile_lds(const Dev &d) { return sizeof(double) * ((size_t)(d.T + 1) * d.TP + (size_t)d.VT * (d.TP + 1)); }
+// direct solver on one GPU: the right-hand-side kernel writes the mode-space right-hand side itself
+inline bool rhs_writes_modes(const Ctx *c) {
+    return c->use_front && c->front.n_nodes > 0 && c->shard_stride == 0 && c->lap_solver == DOTS_LAP_MODAL_PCG && time_modes_tile_ok(c->d);
+}
+
 int64_t array_count_host(const Dev &d, int array_id);    // elements in the reference layout
 int64_t array_count_device(const Dev &d, int array_id);  // elements in the device layout
 int array_kind(int array_id);  // 0 node (T+1,V), 1 interval (T,V), 2 triangle (T+1,F,3), 3 corner (T,2,3,F,3)

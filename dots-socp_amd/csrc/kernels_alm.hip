@@ -88,37 +88,41 @@ int launch_soc_projection(Ctx *c, int zmid_mode) {
 // div_x is a gather over the vertex's corner list (no scatter, no atomics).  Each workgroup also
 // emits the partial sum of b (mean removal for the singular eps = 0 operator).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r, double eps) {
+    const int iv = idxV(d, v, t);
+    const double m = d.mass_v[v];
+    const double ih = 1.0 / d.h;
+    double xt = 0.0, xm = 0.0;
+    if (t < d.T) xt = (d.A[iv] + d.lam[iv] - d.mu[iv]) * m;
+    if (t > 0) xm = (d.A[iv - 1] + d.lam[iv - 1] - d.mu[iv - 1]) * m;
+    double rhs = (xt - xm) * ih;
+    double ds = 0.0;
+    for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+        const int f = d.cidx[j] / 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t i = idxF(d, f, c, t);
+            ds += d.c_gA[j * 3 + c] * (d.B[i] - d.E[i]);
+        }
+    }
+    rhs -= ds;
+    if (t == 0) rhs += d.mu0[v] / (r * d.h);
+    if (t == d.T) rhs -= d.mu1[v] / (r * d.h);
+    rhs -= eps * m * d.phi[iv];
+    return -rhs;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps) {
     __shared__ double lds[4];
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
     double part[1] = {0.0};
     if (tile < d.n_vtiles) {
         const int v0 = tile * d.VT;
-        const double ih = 1.0 / d.h;
         for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
             const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
             if (v >= d.V || t > d.T) continue;
-            const int iv = idxV(d, v, t);
-            const double m = d.mass_v[v];
-            double xt = 0.0, xm = 0.0;
-            if (t < d.T) xt = (d.A[iv] + d.lam[iv] - d.mu[iv]) * m;
-            if (t > 0) xm = (d.A[iv - 1] + d.lam[iv - 1] - d.mu[iv - 1]) * m;
-            double rhs = (xt - xm) * ih;
-            double ds = 0.0;
-            for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
-                const int f = d.cidx[j] / 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int64_t i = idxF(d, f, c, t);
-                    ds += d.c_gA[j * 3 + c] * (d.B[i] - d.E[i]);
-                }
-            }
-            rhs -= ds;
-            if (t == 0) rhs += d.mu0[v] / (r * d.h);
-            if (t == d.T) rhs -= d.mu1[v] / (r * d.h);
-            rhs -= eps * m * d.phi[iv];
-            const double b = -rhs;
-            d.cg_b[iv] = b;
+            const double b = rhs_value(d, v, t, r, eps);
+            d.cg_b[idxV(d, v, t)] = b;
             part[0] += b;
         }
     }
@@ -126,9 +130,52 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps) {
     if (threadIdx.x == 0) d.partials[blockIdx.x] = part[0];
 }
 
+// The same right-hand side followed at once by the time-mode transform of the tile (direct solver, T + 1 <= 64):
+// b never goes to memory, the solver's input  bhat[v][a] = sum_t Q[t][a] b[v][t]  is written instead.
+__global__ __launch_bounds__(BLOCK) void k_rhs_modes(Dev d, double r, double eps, double *__restrict__ bhat) {
+    extern __shared__ double tm_lds[];
+    const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+    double *Qs = tm_lds;                 // [n][TP]
+    double *xs = tm_lds + n * TP;        // [VT][TPp]
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    if (tile >= d.n_vtiles) return;
+    const int tid = threadIdx.x;
+    const int v0 = tile * d.VT;
+    for (int e = tid; e < TILE_ELEMS; e += BLOCK) {
+        const int vl = e >> d.tp_shift, t = e & (TP - 1);
+        xs[vl * TPp + t] = (v0 + vl < d.V && t < n) ? rhs_value(d, v0 + vl, t, r, eps) : 0.0;
+    }
+    for (int e = tid; e < n * TP; e += BLOCK) {
+        const int i = e >> d.tp_shift, j = e & (TP - 1);
+        Qs[e] = j < n ? d.Q[i * n + j] : 0.0;
+    }
+    __syncthreads();
+    const int j = tid & (TP - 1), g = tid >> d.tp_shift, G = BLOCK >> d.tp_shift;
+    if (j >= n) return;
+    for (int vl0 = g; vl0 < d.VT; vl0 += 4 * G) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        const double *x0 = xs + vl0 * TPp;
+        for (int i = 0; i < n; ++i) {
+            const double q = Qs[(i << d.tp_shift) + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (vl0 + k * G < d.VT) acc[k] += q * x0[k * G * TPp + i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = v0 + vl0 + k * G;
+            if (vl0 + k * G < d.VT && v < d.V) bhat[idxV(d, v, j)] = acc[k];
+        }
+    }
+}
+
 int launch_rhs(Ctx *c) {
     const int g = xcd_grid(c->d.n_vtiles);
-    hipLaunchKernelGGL(k_rhs, dim3(g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps);
+    if (rhs_writes_modes(c))
+        hipLaunchKernelGGL(k_rhs_modes, dim3(g), dim3(BLOCK), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps,
+                           c->d.cg_p0);
+    else
+        hipLaunchKernelGGL(k_rhs, dim3(g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps);
     DOTS_HIP(hipGetLastError());
     return 0;
 }
@@ -147,9 +194,15 @@ int launch_rhs(Ctx *c) {
 // Every beta_mid entry is attached to the node whose B it is compared with, so the thread that
 // computes B[t] updates them without any exchange: z_mid and beta_mid are read once, beta_mid written once.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, double sz, double cd, double cr, double tau);
+
 __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_vertex(Dev d, double sz, double cd, double cr, double tau) {
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
+    q_lambda_vertex_tile(d, tile, sz, cd, cr, tau);
+}
+
+__device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, double sz, double cd, double cr, double tau) {
     const int v0 = tile * d.VT;
     const double a1 = sz * (1.0 + cr);
     const double a2 = 1.0 + 2.0 * sz * a1;
@@ -173,8 +226,15 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_vertex(Dev d, double sz
 
 // ZMODE 0: z_mid is read from memory; 1: rebuilt from the cone multiplier (same expression as the projection
 // kernel: z = (lambda / D) * (D * (sz/sqrt3 * B_old - beta_mid))) and stored; 2: rebuilt, not stored.
+// Workgroups [0, nf8) do the triangle part; with VERTEX_TOO the vertex part (independent of it: different
+// arrays) rides in the same launch as workgroups [nf8, nf8 + nv8).
 template <int ZMODE>
-__global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double sz, double tau) {
+__global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double sz, double tau, int nf8, double cd, double cr) {
+    if ((int)blockIdx.x >= nf8) {
+        const int vt = xcd_tile(blockIdx.x - nf8, d.n_vtiles);
+        if (vt < d.n_vtiles) q_lambda_vertex_tile(d, vt, sz, cd, cr, tau);
+        return;
+    }
     const int tile = xcd_tile(blockIdx.x, d.n_ftiles);
     if (tile >= d.n_ftiles) return;
     const int row0 = tile * d.FT;
@@ -233,12 +293,12 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
 
 int launch_q_lambda_mult(Ctx *c, int zmid_mode) {
     const dots_params &p = c->prm;
-    hipLaunchKernelGGL(k_q_lambda_mult_vertex, dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, p.scale_z,
-                       p.const_d, p.congestion * p.r, p.tau);
-    const dim3 gf(xcd_grid(c->d.n_ftiles));
-    if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_triangle<2>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau);
-    else if (zmid_mode == 1) hipLaunchKernelGGL((k_q_lambda_mult_triangle<1>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau);
-    else hipLaunchKernelGGL((k_q_lambda_mult_triangle<0>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau);
+    const int nf8 = xcd_grid(c->d.n_ftiles), nv8 = xcd_grid(c->d.n_vtiles);
+    const dim3 gf(nf8 + nv8);
+    const double cd = p.const_d, cr = p.congestion * p.r;
+    if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_triangle<2>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
+    else if (zmid_mode == 1) hipLaunchKernelGGL((k_q_lambda_mult_triangle<1>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
+    else hipLaunchKernelGGL((k_q_lambda_mult_triangle<0>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
     DOTS_HIP(hipGetLastError());
     return 0;
 }

@@ -465,8 +465,6 @@ __global__ __launch_bounds__(BLOCK) void k_time_modes_tile(Dev d, const double *
         }
     }
 }
-static size_t time_modes_tile_lds(const Dev &d) { return sizeof(double) * ((size_t)(d.T + 1) * d.TP + (size_t)d.VT * (d.TP + 1)); }
-static bool time_modes_tile_ok(const Dev &d) { return d.T + 1 <= 64 && d.TP <= BLOCK && d.VT >= 1; }
 
 // ------------------------------------------------------------------------------------------
 // host driver
@@ -718,7 +716,9 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
     } else {
         if (MODAL) {
             // b^ = Q^T b (into p0 as scratch), x^ = Q^T phi (warm start in mode space)
-            if (direct && time_modes_tile_ok(d))
+            if (rhs_writes_modes(c)) {
+                // k_rhs_modes (kernels_alm.hip) already left the mode-space right-hand side in cg_p0
+            } else if (direct && time_modes_tile_ok(d))
                 hipLaunchKernelGGL((k_time_modes_tile<true>), dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, d.cg_b, d.cg_p0);
             else
                 hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_b, d.cg_p0, 1);
