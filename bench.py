@@ -32,6 +32,10 @@ WORKLOADS = {
     "knot": dict(example="knot", kw={}, n_time=31, congestion=0.0, tol=1e-3),
     # configs[3]: ~100k-vertex torus, ntime=31
     "torus100k": dict(example="torus", kw=dict(nu=400, nv=250), n_time=31, congestion=0.0, tol=1e-3),
+    # configs[2]: knots mesh, ntime=63, congestion 0.1 (time pitch 64)
+    "knot63": dict(example="knot", kw={}, n_time=63, congestion=0.1, tol=1e-3),
+    # configs[4] stand-in: 360 x 180 torus, V = 64 800, ntime=127 (time pitch 128), tol 1e-5
+    "torus65k_T127": dict(example="torus", kw=dict(nu=360, nv=180), n_time=127, congestion=0.0, tol=1e-5),
     # the survey's analytic case
     "plane20": dict(example="plane", kw=dict(n=20), n_time=31, congestion=0.0, tol=1e-3),
 }

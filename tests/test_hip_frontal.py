@@ -66,3 +66,29 @@ def test_direct_solver_is_deterministic_and_exact():
         got.append(dev.download("phi"))
         dev.close()
     assert np.array_equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("T", [63, 127, 20])
+def test_time_pitches_64_128_and_ragged(T):
+    """T = 63 / 127 (time pitch 64 / 128: BASELINE configs 3 and 5) and T = 20 (pitch 32 with 11 padding columns):
+    ten full ALM iterations with the direct solver stay on the oracle's trajectory."""
+    from conftest import load_oracle
+    from dots_socp_amd.device import DeviceProblem
+
+    O = load_oracle()
+    geom, _ = meshes.example("sphere", level=2)
+    s = O.OracleSolver(T, geom, congestion=0.02)
+    s.scale_z(2.0)
+    dev = DeviceProblem(T, geom, lap_solver="modal_pcg", reorder="nd", nd_leaf=8)
+    assert dev.setup_frontal()["levels"] >= 4
+    dev.scale_z(2.0, 0.5, 2.0)
+    dev.set_params(scale_z=2.0, const_d=2.0, norm_d=s.norm_d, congestion=0.02)
+    for _ in range(10):
+        s.iterate()
+    dev.step(10)
+    for k in ("A", "B", "mu", "E", "z_mid", "beta_mid"):
+        assert rel(dev.download(k), getattr(s, k)) < 1e-8, (T, k)
+    want, got = s.kkt_all(), dev.kkt(range(7))
+    for i in range(7):
+        assert abs(got[i][0] - want[i]) <= 1e-7 * abs(want[i]) + 1e-14, (T, i)
+    dev.close()
