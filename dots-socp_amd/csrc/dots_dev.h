@@ -217,9 +217,10 @@ struct Ctx {
     }
 };
 
-// T + 1 <= 64: the time-mode transforms stage Q and a tile of rows in LDS (k_time_modes_tile, k_rhs_modes)
-inline bool time_modes_tile_ok(const Dev &d) { return d.T + 1 <= 64 && d.TP <= BLOCK && d.VT >= 1; }
-inline size_t time_modes_tile_lds(const Dev &d) { return sizeof(double) * ((size_t)(d.T + 1) * d.TP + (size_t)d.VT * (d.TP + 1)); }
+// The time-mode transforms stage a tile of rows and Q (in chunks of <= 32 KB) in LDS (k_time_modes_tile, k_rhs_modes)
+inline bool time_modes_tile_ok(const Dev &d) { return d.TP <= BLOCK && d.VT >= 1; }
+inline int time_modes_chunk(const Dev &d) { return (4096 / d.TP) < (d.T + 1) ? (4096 / d.TP) : (d.T + 1); }    // rows of Q per chunk
+inline size_t time_modes_tile_lds(const Dev &d) { return sizeof(double) * ((size_t)time_modes_chunk(d) * d.TP + (size_t)d.VT * (d.TP + 1)); }
 // direct solver on one GPU: the right-hand-side kernel writes the mode-space right-hand side itself
 inline bool rhs_writes_modes(const Ctx *c) {
     return c->use_front && c->front.n_nodes > 0 && c->shard_stride == 0 && c->lap_solver == DOTS_LAP_MODAL_PCG && time_modes_tile_ok(c->d);
@@ -266,6 +267,41 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double *lds /* [N*4] *
         for (int i = 0; i < N; ++i) v[i] = (lds[i * 4] + lds[i * 4 + 1]) + (lds[i * 4 + 2] + lds[i * 4 + 3]);
     }
 }
+// y[v0 + vl][j] = sum_i Qeff[i][j] xs[vl][i] for the tile staged in xs ([VT][TP + 1], zero padded), with
+// Qeff[i][j] = Q[i][j] (FWD: time -> modes) or Q[j][i] (modes -> time), staged through Qs in chunks of IC rows.
+// A thread computes up to four outputs that share their Q column.  All threads of the workgroup must call it.
+template <bool FWD>
+__device__ __forceinline__ void modes_from_tile(const Dev &d, const double *Q, const double *xs, double *Qs, int IC, int v0, double *__restrict__ y) {
+    const int n = d.T + 1, TP = d.TP, TPp = TP + 1, tid = threadIdx.x;
+    const int j = tid & (TP - 1), g = tid >> d.tp_shift, G = BLOCK >> d.tp_shift;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = 0; i0 < n; i0 += IC) {
+        const int ic = min(IC, n - i0);
+        __syncthreads();      // the previous chunk (or the caller's staging of xs) is complete
+        for (int e = tid; e < ic * TP; e += BLOCK) {
+            const int i = i0 + (e >> d.tp_shift), jj = e & (TP - 1);
+            Qs[e] = jj < n ? (FWD ? Q[i * n + jj] : Q[jj * n + i]) : 0.0;
+        }
+        __syncthreads();
+        if (j < n && g < d.VT) {
+            const double *x0 = xs + g * TPp + i0;
+            for (int i = 0; i < ic; ++i) {
+                const double q = Qs[(i << d.tp_shift) + j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (g + r * G < d.VT) acc[r] += q * x0[r * G * TPp + i];
+            }
+        }
+    }
+    if (j < n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int vl = g + r * G;
+            if (vl < d.VT && v0 + vl < d.V) y[idxV(d, v0 + vl, j)] = acc[r];
+        }
+    }
+}
+
 #endif
 
 }  // namespace dots

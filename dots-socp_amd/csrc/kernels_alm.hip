@@ -130,50 +130,28 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps) {
     if (threadIdx.x == 0) d.partials[blockIdx.x] = part[0];
 }
 
-// The same right-hand side followed at once by the time-mode transform of the tile (direct solver, T + 1 <= 64):
-// b never goes to memory, the solver's input  bhat[v][a] = sum_t Q[t][a] b[v][t]  is written instead.
-__global__ __launch_bounds__(BLOCK) void k_rhs_modes(Dev d, double r, double eps, double *__restrict__ bhat) {
+// The same right-hand side followed at once by the time-mode transform of the tile (direct solver): b never goes
+// to memory, the solver's input  bhat[v][a] = sum_t Q[t][a] b[v][t]  is written instead.
+__global__ __launch_bounds__(BLOCK) void k_rhs_modes(Dev d, double r, double eps, double *__restrict__ bhat, int IC) {
     extern __shared__ double tm_lds[];
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
-    double *Qs = tm_lds;                 // [n][TP]
-    double *xs = tm_lds + n * TP;        // [VT][TPp]
+    double *Qs = tm_lds;                 // [IC][TP]
+    double *xs = tm_lds + IC * TP;       // [VT][TPp]
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
-    const int tid = threadIdx.x;
     const int v0 = tile * d.VT;
-    for (int e = tid; e < TILE_ELEMS; e += BLOCK) {
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
         const int vl = e >> d.tp_shift, t = e & (TP - 1);
         xs[vl * TPp + t] = (v0 + vl < d.V && t < n) ? rhs_value(d, v0 + vl, t, r, eps) : 0.0;
     }
-    for (int e = tid; e < n * TP; e += BLOCK) {
-        const int i = e >> d.tp_shift, j = e & (TP - 1);
-        Qs[e] = j < n ? d.Q[i * n + j] : 0.0;
-    }
-    __syncthreads();
-    const int j = tid & (TP - 1), g = tid >> d.tp_shift, G = BLOCK >> d.tp_shift;
-    if (j >= n) return;
-    for (int vl0 = g; vl0 < d.VT; vl0 += 4 * G) {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        const double *x0 = xs + vl0 * TPp;
-        for (int i = 0; i < n; ++i) {
-            const double q = Qs[(i << d.tp_shift) + j];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (vl0 + k * G < d.VT) acc[k] += q * x0[k * G * TPp + i];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int v = v0 + vl0 + k * G;
-            if (vl0 + k * G < d.VT && v < d.V) bhat[idxV(d, v, j)] = acc[k];
-        }
-    }
+    modes_from_tile<true>(d, d.Q, xs, Qs, IC, v0, bhat);
 }
 
 int launch_rhs(Ctx *c) {
     const int g = xcd_grid(c->d.n_vtiles);
     if (rhs_writes_modes(c))
         hipLaunchKernelGGL(k_rhs_modes, dim3(g), dim3(BLOCK), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps,
-                           c->d.cg_p0);
+                           c->d.cg_p0, time_modes_chunk(c->d));
     else
         hipLaunchKernelGGL(k_rhs, dim3(g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps);
     DOTS_HIP(hipGetLastError());

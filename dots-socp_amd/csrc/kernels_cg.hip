@@ -425,45 +425,23 @@ __global__ __launch_bounds__(BLOCK) void k_time_modes(Dev d, const double *__res
     }
 }
 
-// The same transform with Q and the tile of x staged in LDS (T + 1 <= 64): every x row and every Q entry is
-// read from memory once per workgroup instead of once per output; a thread computes four outputs that share
-// their Q column.  x rows are padded by one double so that the rows a wavefront broadcasts sit in different banks.
+// The same transform with the tile of x and Q (in chunks) staged in LDS: every x row and every Q entry is read
+// from memory once per workgroup instead of once per output; a thread computes four outputs that share their Q
+// column.  x rows are padded by one double so that the rows a wavefront broadcasts sit in different banks.
 template <bool FWD>
-__global__ __launch_bounds__(BLOCK) void k_time_modes_tile(Dev d, const double *__restrict__ x, double *__restrict__ y) {
+__global__ __launch_bounds__(BLOCK) void k_time_modes_tile(Dev d, const double *__restrict__ x, double *__restrict__ y, int IC) {
     extern __shared__ double tm_lds[];
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
-    double *Qs = tm_lds;                 // [n][TP]   Qs[i][j] = coefficient of x[.][i] in y[.][j]
-    double *xs = tm_lds + n * TP;        // [VT][TPp]
+    double *Qs = tm_lds;                 // [IC][TP]
+    double *xs = tm_lds + IC * TP;       // [VT][TPp]
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < n * TP; e += BLOCK) {
-        const int i = e >> d.tp_shift, j = e & (TP - 1);
-        Qs[e] = j < n ? (FWD ? d.Q[i * n + j] : d.Q[j * n + i]) : 0.0;
-    }
     const int v0 = tile * d.VT;
-    for (int e = tid; e < TILE_ELEMS; e += BLOCK) {
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
         const int vl = e >> d.tp_shift, t = e & (TP - 1);
         xs[vl * TPp + t] = (v0 + vl < d.V && t < n) ? x[idxV(d, v0 + vl, t)] : 0.0;
     }
-    __syncthreads();
-    const int j = tid & (TP - 1), g = tid >> d.tp_shift, G = BLOCK >> d.tp_shift;   // G row groups; a thread takes rows g, g+G, ...
-    if (j >= n) return;
-    for (int vl0 = g; vl0 < d.VT; vl0 += 4 * G) {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        const double *x0 = xs + vl0 * TPp;
-        for (int i = 0; i < n; ++i) {
-            const double q = Qs[(i << d.tp_shift) + j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (vl0 + r * G < d.VT) acc[r] += q * x0[r * G * TPp + i];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int v = v0 + vl0 + r * G;
-            if (vl0 + r * G < d.VT && v < d.V) y[idxV(d, v, j)] = acc[r];
-        }
-    }
+    modes_from_tile<FWD>(d, d.Q, xs, Qs, IC, v0, y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -719,7 +697,7 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
             if (rhs_writes_modes(c)) {
                 // k_rhs_modes (kernels_alm.hip) already left the mode-space right-hand side in cg_p0
             } else if (direct && time_modes_tile_ok(d))
-                hipLaunchKernelGGL((k_time_modes_tile<true>), dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, d.cg_b, d.cg_p0);
+                hipLaunchKernelGGL((k_time_modes_tile<true>), dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, d.cg_b, d.cg_p0, time_modes_chunk(d));
             else
                 hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_b, d.cg_p0, 1);
             if (!direct) hipLaunchKernelGGL((k_time_modes<true>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.phi, d.cg_x, 0);
@@ -741,7 +719,7 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
     if (rc) return rc;
     if (MODAL && !sharded) {
         if (time_modes_tile_ok(d))
-            hipLaunchKernelGGL((k_time_modes_tile<false>), dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, d.cg_x, d.phi);
+            hipLaunchKernelGGL((k_time_modes_tile<false>), dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, d.cg_x, d.phi, time_modes_chunk(d));
         else
             hipLaunchKernelGGL((k_time_modes<false>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_x, d.phi, 0);
         DOTS_HIP(hipGetLastError());
