@@ -126,3 +126,23 @@ def test_warm_start_is_a_fixed_point():
     sol2, hist2 = solver_socp(8, geom, nit=3000, tol=1e-3, is_z_scaling=False, init_solution=init)
     assert int(hist2.kkt_iteration[-1]) < max(5, n1 // 10)
     assert abs(hist2.history["Transportation cost"][-1] - hist.history["Transportation cost"][-1]) < 1e-3
+
+
+def test_plane_against_the_exact_transport():
+    """Ground truth independent of the reference (interface.py:386-480, data/settings/plane.py):
+    two equal Gaussians on the plane -> a translation, dynamic cost 0.04, displacement interpolation in between."""
+    from dots_socp_amd import evaluate, meshes
+    from dots_socp_amd.socp import solver
+
+    T = 31
+    geom, scale = meshes.example("plane", n=40)
+    sol, hist = solver(T, geom, tol=1e-4, nit=5000)
+    cost = hist.history["Transportation cost"][-1] / scale ** 2
+    assert abs(cost - 0.04) < 1e-4
+    assert sol["mu"].shape == (T + 2, geom["vertices"].shape[0])
+    tt = np.concatenate([[0.0], (np.arange(T) + 0.5) / T, [1.0]])
+    exact = evaluate.plane_exact_transportation(tt, geom["vertices"] / scale, geom["area_vertices"])
+    err = evaluate.compare_with_exact_transportation(sol["mu"], exact, geom["area_vertices"])
+    assert err["l1"] < 1e-2 and err["l2"] < 1e-2 and err["linf"] < 5e-2
+    assert evaluate.check_mass_conservation(sol["mu"])[0] < 1e-4
+    assert evaluate.check_negative_mass(sol["mu"])[0] < 1e-5

@@ -228,3 +228,30 @@ def test_mesh_generators():
     assert abs(g["mu0"].sum() - 1) < 1e-14 and abs(g["mu1"].sum() - 1) < 1e-14
     assert np.allclose(g["vertices"].min(0), 0) and abs(g["vertices"].max() - 1) < 1e-14 and scale == pytest.approx(0.5)
     assert meshes.icosphere(5)[0].shape[0] == 10242 and meshes.torus(400, 250)[0].shape[0] == 100000
+
+
+def test_evaluate_helpers():
+    """dots-socp_amd/evaluate.py against direct numpy formulas (evaluate_solution.py:7-58)."""
+    from dots_socp_amd import evaluate, meshes
+
+    v, t = meshes.plane(10)
+    at = meshes.triangle_areas(v, t)
+    av = meshes.vertex_areas(v.shape[0], t, at)
+    tt = np.array([0.0, 0.25, 1.0])
+    mu = evaluate.plane_exact_transportation(tt, v, av)
+    assert mu.shape == (3, v.shape[0]) and np.allclose(mu.sum(axis=1), 1.0)
+    assert np.allclose(mu[0], meshes.gaussian_density(v, av, [0.4, 0.4, 0.0], 0.02))
+    assert np.argmax(mu[2] / av) == np.argmin(np.sum((v - np.array([0.6, 0.6, 0.0])) ** 2, axis=1))
+    err, mass = evaluate.check_mass_conservation(np.array([[0.5, 0.5], [0.75, 0.5]]))
+    assert np.allclose(mass, [1.0, 1.25]) and abs(err - 0.25 / np.sqrt(2)) < 1e-15
+    err, neg = evaluate.check_negative_mass(np.array([[0.5, -0.25, -0.25], [1.0, 0.0, 0.0]]))
+    assert np.allclose(neg, [-0.5, 0.0]) and abs(err - 0.5 / np.sqrt(2)) < 1e-15
+    d = evaluate.compare_with_exact_transportation(mu, mu, av)
+    assert d == {"l1": 0.0, "l2": 0.0, "linf": 0.0}
+    pert = mu.copy()
+    pert[1, 7] += 1e-3
+    d = evaluate.compare_with_exact_transportation(pert, mu, av)
+    w = av / 3.0
+    rho = mu / w
+    assert abs(d["l1"] - 1e-3 / (1.0 + np.sum(np.abs(rho) * w))) < 1e-15
+    assert abs(d["linf"] - (1e-3 / w[7]) / (1.0 + rho.max())) < 1e-12
