@@ -70,7 +70,8 @@ __device__ __forceinline__ double front_folded(const double *red, int r, int TP,
 // Every load of the loop body is unconditional (rows past the block are clamped to its first row and their sums
 // dropped; leaves read their "children's" planes from the zero pad at the start of W; the upper triangle of L^-1
 // is stored as zeros), so that the compiler issues the RB + 3 loads of a step back to back and waits once.
-template <int NB, int RB, bool VMAP>
+// RB is the level's exact block size (1, 2 or 4: no duplicate loads); LEAF (tree height 0): no update planes to read.
+template <int NB, int RB, bool VMAP, bool LEAF>
 __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const int2 *__restrict__ desc, int rb, const double *__restrict__ bhat,
                                                   double *__restrict__ Y) {
     __shared__ double red[RB * (NB / 64) * 64];
@@ -101,11 +102,11 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
             const int64_t jo = (int64_t)j << sh;
             const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
             const double wb = bhat[(row << sh) + a];
-            const double w0 = W0[jo], w1 = W0[plane + jo];
+            const double w0 = LEAF ? 0.0 : W0[jo], w1 = LEAF ? 0.0 : W0[plane + jo];
             double fv[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) fv[r] = rowp[r][jo];
-            const double w = wb - (w0 + w1);
+            const double w = LEAF ? wb : wb - (w0 + w1);
 #pragma unroll
             for (int r = 0; r < RB; ++r) acc[r] += fv[r] * w;
         }
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
         if (i < n) {
             Y[(front_row(f, nd.k0 + i) << sh) + a] = s;
         } else {   // update row: carry the children's contributions on, hand the sum to the parent's plane
-            s += W0[(int64_t)i << sh] + W0[plane + ((int64_t)i << sh)];
+            if (!LEAF) s += W0[(int64_t)i << sh] + W0[plane + ((int64_t)i << sh)];
             f.W[((nd.parent_w + f.cmap[nd.bdoff + (i - n)]) << sh) + a] = s;
         }
     }
@@ -341,7 +342,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         // record, loads, fold, store) then covers 4x more bytes
         const int rbmax = c->front_rb_max;
         auto block = [rbmax](int64_t total) {
-            int b = total >= 16384 ? 16 : (total >= 8192 ? 8 : (total >= 4096 ? 4 : (total >= 2048 ? 2 : 1)));
+            int b = total >= 4096 ? 4 : (total >= 2048 ? 2 : 1);
             return std::min(b, rbmax);
         };
         const int rb = block(rows), cb = block(cols);
@@ -395,32 +396,40 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
     if (f.n_nodes == 0) { set_error("front_solve: no factor installed"); return DOTS_ERR_STATE; }
     const FrontArgs g{d.tp_shift, d.TP, d.cg_ncol};
     const bool vm = f.vmap != nullptr;
-#define FRONT_LAUNCH(K, NBV, RBV, ptr, blk, ...)                                                                                   \
+#define FRONT_FWD(NBV, RBV, LEAFV)                                                                                                 \
     do {                                                                                                                           \
-        if (vm) hipLaunchKernelGGL((K<NBV, RBV, true>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, __VA_ARGS__);            \
-        else hipLaunchKernelGGL((K<NBV, RBV, false>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, __VA_ARGS__);              \
+        if (vm) hipLaunchKernelGGL((k_front_fwd<NBV, RBV, true, LEAFV>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);  \
+        else hipLaunchKernelGGL((k_front_fwd<NBV, RBV, false, LEAFV>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);    \
+    } while (0)
+#define FRONT_BWD(NBV, RBV)                                                                                                        \
+    do {                                                                                                                           \
+        if (vm) hipLaunchKernelGGL((k_front_bwd<NBV, RBV, true>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);         \
+        else hipLaunchKernelGGL((k_front_bwd<NBV, RBV, false>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);           \
     } while (0)
     for (int l = 0; l < f.n_levels; ++l) {
         const int n = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
         if (n <= 0) continue;
         const int2 *ptr = f.fwd_desc + c->front_fwd_ptr[l];
         const int blk = c->front_fwd_rb[l];
-        if (c->front_fwd_nb[l] == 1024) FRONT_LAUNCH(k_front_fwd, 1024, 4, ptr, blk, bhat, y);
-        else if (blk > 8) FRONT_LAUNCH(k_front_fwd, 256, 16, ptr, blk, bhat, y);
-        else if (blk > 4) FRONT_LAUNCH(k_front_fwd, 256, 8, ptr, blk, bhat, y);
-        else FRONT_LAUNCH(k_front_fwd, 256, 4, ptr, blk, bhat, y);
+        const bool big = c->front_fwd_nb[l] == 1024;
+        if (l == 0) {            // height 0: leaves only
+            if (big) { if (blk == 1) FRONT_FWD(1024, 1, true); else if (blk == 2) FRONT_FWD(1024, 2, true); else FRONT_FWD(1024, 4, true); }
+            else { if (blk == 1) FRONT_FWD(256, 1, true); else if (blk == 2) FRONT_FWD(256, 2, true); else FRONT_FWD(256, 4, true); }
+        } else {
+            if (big) { if (blk == 1) FRONT_FWD(1024, 1, false); else if (blk == 2) FRONT_FWD(1024, 2, false); else FRONT_FWD(1024, 4, false); }
+            else { if (blk == 1) FRONT_FWD(256, 1, false); else if (blk == 2) FRONT_FWD(256, 2, false); else FRONT_FWD(256, 4, false); }
+        }
     }
     for (int l = f.n_levels - 1; l >= 0; --l) {
         const int n = c->front_bwd_ptr[l + 1] - c->front_bwd_ptr[l];
         if (n <= 0) continue;
         const int2 *ptr = f.bwd_desc + c->front_bwd_ptr[l];
         const int blk = c->front_bwd_cb[l];
-        if (c->front_bwd_nb[l] == 1024) FRONT_LAUNCH(k_front_bwd, 1024, 4, ptr, blk, y, x);
-        else if (blk > 8) FRONT_LAUNCH(k_front_bwd, 256, 16, ptr, blk, y, x);
-        else if (blk > 4) FRONT_LAUNCH(k_front_bwd, 256, 8, ptr, blk, y, x);
-        else FRONT_LAUNCH(k_front_bwd, 256, 4, ptr, blk, y, x);
+        if (c->front_bwd_nb[l] == 1024) { if (blk == 1) FRONT_BWD(1024, 1); else if (blk == 2) FRONT_BWD(1024, 2); else FRONT_BWD(1024, 4); }
+        else { if (blk == 1) FRONT_BWD(256, 1); else if (blk == 2) FRONT_BWD(256, 2); else FRONT_BWD(256, 4); }
     }
-#undef FRONT_LAUNCH
+#undef FRONT_FWD
+#undef FRONT_BWD
     DOTS_HIP(hipGetLastError());
     return 0;
 }

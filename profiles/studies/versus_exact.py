@@ -21,8 +21,7 @@ for n, T in ((20, 31), (40, 31), (80, 63), (160, 63), (240, 127)):
     sol, hist = solver(T, geom, tol=tol, nit=20000)
     sec = time.perf_counter() - t0
     cost = hist.history["Transportation cost"][-1] / scale ** 2
-    tt = np.linspace(0.0, 1.0, T + 2)           # centred grid: mu0, T + 1 - 1 midpoints ... (T + 2 layers)
-    tt = np.concatenate([[0.0], (np.arange(T) + 0.5) / T, [1.0]]) if sol["mu"].shape[0] == T + 2 else np.linspace(0, 1, sol["mu"].shape[0])
+    tt = np.linspace(0.0, 1.0, sol["mu"].shape[0])           # time-centred grid: the T + 1 nodes
     exact = evaluate.plane_exact_transportation(tt, geom["vertices"] / scale, geom["area_vertices"])
     err = evaluate.compare_with_exact_transportation(sol["mu"], exact, geom["area_vertices"])
     mass, _ = evaluate.check_mass_conservation(sol["mu"])

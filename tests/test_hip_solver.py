@@ -139,8 +139,8 @@ def test_plane_against_the_exact_transport():
     sol, hist = solver(T, geom, tol=1e-4, nit=5000)
     cost = hist.history["Transportation cost"][-1] / scale ** 2
     assert abs(cost - 0.04) < 1e-4
-    assert sol["mu"].shape == (T + 2, geom["vertices"].shape[0])
-    tt = np.concatenate([[0.0], (np.arange(T) + 0.5) / T, [1.0]])
+    assert sol["mu"].shape == (T + 1, geom["vertices"].shape[0])      # time-centred grid: the T + 1 nodes
+    tt = np.linspace(0.0, 1.0, T + 1)
     exact = evaluate.plane_exact_transportation(tt, geom["vertices"] / scale, geom["area_vertices"])
     err = evaluate.compare_with_exact_transportation(sol["mu"], exact, geom["area_vertices"])
     assert err["l1"] < 1e-2 and err["l2"] < 1e-2 and err["linf"] < 5e-2
