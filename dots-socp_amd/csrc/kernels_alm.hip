@@ -20,11 +20,15 @@ namespace dots {
 // 18*T*F loads disappear there.
 template <bool ONLY_MULTIPLIER>
 __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, double cd) {
-    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    // one element per thread: a workgroup takes a quarter of a tile (the corner walk is a chain of dependent
+    // loads; four elements per thread would serialise four of them)
+    // (block b and block b + G8 share a tile and an XCD: G8 is a multiple of 8)
+    const int G8 = gridDim.x / (TILE_ELEMS / BLOCK);
+    const int tile = xcd_tile(blockIdx.x % G8, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
     const int v0 = tile * d.VT;
     const double sB = sz * INV_SQRT3;
-    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+    for (int e = (blockIdx.x / G8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
         const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
         if (v >= d.V || t >= d.T) continue;
         const int iv = idxV(d, v, t);
@@ -72,11 +76,11 @@ __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, doub
 
 int launch_soc_projection(Ctx *c, int zmid_mode) {
     if (zmid_mode)
-        hipLaunchKernelGGL((k_soc_projection<true>), dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, c->prm.scale_z,
-                           c->prm.const_d);
+        hipLaunchKernelGGL((k_soc_projection<true>), dim3(xcd_grid(c->d.n_vtiles) * (TILE_ELEMS / BLOCK)), dim3(BLOCK), 0, c->stream, c->d,
+                           c->prm.scale_z, c->prm.const_d);
     else
-        hipLaunchKernelGGL((k_soc_projection<false>), dim3(xcd_grid(c->d.n_vtiles)), dim3(BLOCK), 0, c->stream, c->d, c->prm.scale_z,
-                           c->prm.const_d);
+        hipLaunchKernelGGL((k_soc_projection<false>), dim3(xcd_grid(c->d.n_vtiles) * (TILE_ELEMS / BLOCK)), dim3(BLOCK), 0, c->stream, c->d,
+                           c->prm.scale_z, c->prm.const_d);
     DOTS_HIP(hipGetLastError());
     return 0;
 }
@@ -208,17 +212,18 @@ __device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, dou
 // arrays) rides in the same launch as workgroups [nf8, nf8 + nv8).
 template <int ZMODE>
 __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double sz, double tau, int nf8, double cd, double cr) {
-    if ((int)blockIdx.x >= nf8) {
-        const int vt = xcd_tile(blockIdx.x - nf8, d.n_vtiles);
+    constexpr int SUB = TILE_ELEMS / BLOCK;     // one element per thread: a workgroup takes a quarter of a triangle tile
+    if ((int)blockIdx.x >= nf8 * SUB) {
+        const int vt = xcd_tile(blockIdx.x - nf8 * SUB, d.n_vtiles);
         if (vt < d.n_vtiles) q_lambda_vertex_tile(d, vt, sz, cd, cr, tau);
         return;
     }
-    const int tile = xcd_tile(blockIdx.x, d.n_ftiles);
+    const int tile = xcd_tile(blockIdx.x % nf8, d.n_ftiles);
     if (tile >= d.n_ftiles) return;
     const int row0 = tile * d.FT;
     const double sB = sz * INV_SQRT3;
     const double diag_in = 1.0 + 2.0 * sz * sz, diag_bd = 1.0 + sz * sz;
-    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+    for (int e = (blockIdx.x / nf8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
         const int row = row0 + (e >> d.tp_shift), t = e & (d.TP - 1);
         if (row >= 3 * d.F || t > d.T) continue;
         const int f = row / 3, c = row - 3 * f;
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
 int launch_q_lambda_mult(Ctx *c, int zmid_mode) {
     const dots_params &p = c->prm;
     const int nf8 = xcd_grid(c->d.n_ftiles), nv8 = xcd_grid(c->d.n_vtiles);
-    const dim3 gf(nf8 + nv8);
+    const dim3 gf(nf8 * (TILE_ELEMS / BLOCK) + nv8);
     const double cd = p.const_d, cr = p.congestion * p.r;
     if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_triangle<2>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
     else if (zmid_mode == 1) hipLaunchKernelGGL((k_q_lambda_mult_triangle<1>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
