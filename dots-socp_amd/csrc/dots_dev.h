@@ -270,15 +270,15 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double *lds /* [N*4] *
 // y[v0 + vl][j] = sum_i Qeff[i][j] xs[vl][i] for the tile staged in xs ([VT][TP + 1], zero padded), with
 // Qeff[i][j] = Q[i][j] (FWD: time -> modes) or Q[j][i] (modes -> time), staged through Qs in chunks of IC rows.
 // A thread computes up to four outputs that share their Q column.  All threads of the workgroup must call it.
-template <bool FWD>
+template <bool FWD, int NB = BLOCK>
 __device__ __forceinline__ void modes_from_tile(const Dev &d, const double *Q, const double *xs, double *Qs, int IC, int v0, double *__restrict__ y) {
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1, tid = threadIdx.x;
-    const int j = tid & (TP - 1), g = tid >> d.tp_shift, G = BLOCK >> d.tp_shift;
+    const int j = tid & (TP - 1), g = tid >> d.tp_shift, G = NB >> d.tp_shift;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i0 = 0; i0 < n; i0 += IC) {
         const int ic = min(IC, n - i0);
         __syncthreads();      // the previous chunk (or the caller's staging of xs) is complete
-        for (int e = tid; e < ic * TP; e += BLOCK) {
+        for (int e = tid; e < ic * TP; e += NB) {
             const int i = i0 + (e >> d.tp_shift), jj = e & (TP - 1);
             Qs[e] = jj < n ? (FWD ? Q[i * n + jj] : Q[jj * n + i]) : 0.0;
         }

@@ -136,7 +136,9 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps) {
 
 // The same right-hand side followed at once by the time-mode transform of the tile (direct solver): b never goes
 // to memory, the solver's input  bhat[v][a] = sum_t Q[t][a] b[v][t]  is written instead.
-__global__ __launch_bounds__(BLOCK) void k_rhs_modes(Dev d, double r, double eps, double *__restrict__ bhat, int IC) {
+// 1024 threads: one right-hand-side value (a corner walk) per thread.
+constexpr int RHS_NB = 1024;
+__global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double eps, double *__restrict__ bhat, int IC) {
     extern __shared__ double tm_lds[];
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
     double *Qs = tm_lds;                 // [IC][TP]
@@ -144,17 +146,17 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_modes(Dev d, double r, double eps
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
     const int v0 = tile * d.VT;
-    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += RHS_NB) {
         const int vl = e >> d.tp_shift, t = e & (TP - 1);
         xs[vl * TPp + t] = (v0 + vl < d.V && t < n) ? rhs_value(d, v0 + vl, t, r, eps) : 0.0;
     }
-    modes_from_tile<true>(d, d.Q, xs, Qs, IC, v0, bhat);
+    modes_from_tile<true, RHS_NB>(d, d.Q, xs, Qs, IC, v0, bhat);
 }
 
 int launch_rhs(Ctx *c) {
     const int g = xcd_grid(c->d.n_vtiles);
     if (rhs_writes_modes(c))
-        hipLaunchKernelGGL(k_rhs_modes, dim3(g), dim3(BLOCK), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps,
+        hipLaunchKernelGGL(k_rhs_modes, dim3(g), dim3(RHS_NB), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps,
                            c->d.cg_p0, time_modes_chunk(c->d));
     else
         hipLaunchKernelGGL(k_rhs, dim3(g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps);
