@@ -21,7 +21,7 @@ def _view(ptr, count):
 
 
 class FakeDeviceProblem:
-    def __init__(self, n_time, geometry, lap_solver="modal_pcg", device=0, reorder=True, plan=None, mode_shard=None):
+    def __init__(self, n_time, geometry, lap_solver="modal_pcg", device=0, reorder=True, plan=None, mode_shard=None, **_ignored):
         from dots_socp_amd.geometry import time_modes
 
         self.s = O.OracleSolver(n_time, geometry)
