@@ -29,6 +29,7 @@ struct FactArgs {
     const int *pull0, *pull1;   // front position -> row in the child's boundary, or -1
     double *C, *T, *S;          // work copy of the fronts (becomes L), final factor, Schur complements
     const int *level_nodes;     // nodes of the current height
+    int *bad_pivot;             // set to 1 when a pivot is not positive (operator not positive definite)
 };
 
 __device__ __forceinline__ int front_vertex(const FrontDev &f, const FrontNode &nd, int i) {
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(256) void k_fact_panel(FactArgs g, FrontDev f, int 
     __syncthreads();
     if (FACTOR) {
         for (int t = 0; t < we; ++t) {
-            const double piv = live ? sqrt(Dd(t, t)) : 1.0;
+            const double dtt = live ? Dd(t, t) : 1.0;
+            if (q == 0 && !(dtt > 0.0)) *g.bad_pivot = 1;      // also catches NaN; every writer stores the same value
+            const double piv = sqrt(dtt);
             __syncthreads();
             if (live) {
                 if (q == 0) Dd(t, t) = piv;
@@ -254,11 +257,12 @@ int front_factorize(Ctx *c, const dots_front_desc *h, FrontDev &f, const std::ve
     };
     int64_t srows = 0;
     for (const FrontNode &nd : nodes) srows = std::max(srows, nd.soff + (int64_t)nd.b * nd.b);
-    void *C = nullptr, *S = nullptr, *p0 = nullptr, *p1 = nullptr, *ln = nullptr, *gr = nullptr;
+    void *C = nullptr, *S = nullptr, *p0 = nullptr, *p1 = nullptr, *ln = nullptr, *gr = nullptr, *bp = nullptr;
     if ((rc = dalloc(&C, sizeof(double) * ((size_t)h->n_entries << sh), nullptr)) ||
         (rc = dalloc(&S, sizeof(double) * ((size_t)std::max<int64_t>(srows, 1) << sh), nullptr)) ||
         (rc = dalloc(&p0, sizeof(int) * (size_t)h->n_front_rows, h->pull0)) || (rc = dalloc(&p1, sizeof(int) * (size_t)h->n_front_rows, h->pull1)) ||
-        (rc = dalloc(&ln, sizeof(int) * (size_t)h->n_nodes, h->level_nodes)) || (rc = dalloc(&gr, sizeof(int) * (size_t)d.TP, grounded_host))) {
+        (rc = dalloc(&ln, sizeof(int) * (size_t)h->n_nodes, h->level_nodes)) || (rc = dalloc(&gr, sizeof(int) * (size_t)d.TP, grounded_host)) ||
+        (rc = dalloc(&bp, sizeof(int), nullptr))) {
         release();
         return rc;
     }
@@ -268,6 +272,7 @@ int front_factorize(Ctx *c, const dots_front_desc *h, FrontDev &f, const std::ve
     g.rowptr = d.rowptr; g.col = d.col; g.val = d.val; g.mass = d.mass_v;
     g.pull0 = (const int *)p0; g.pull1 = (const int *)p1;
     g.C = (double *)C; g.T = T; g.S = (double *)S;
+    g.bad_pivot = (int *)bp;
     // panel width: the diagonal block of all modes must fit in LDS (w * w * TP doubles <= 64 KB)
     int w = 16;
     while ((size_t)w * w * d.TP * sizeof(double) > 65536 && w > 1) w /= 2;
@@ -302,10 +307,18 @@ int front_factorize(Ctx *c, const dots_front_desc *h, FrontDev &f, const std::ve
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = hip_fail(e, "factorisation launch", __FILE__, __LINE__);
     }
-    hipError_t e = hipStreamSynchronize(c->stream);
+    int bad = 0;
+    hipError_t e = hipMemcpyAsync(&bad, bp, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
     release();
     if (rc) return rc;
     DOTS_HIP(e);
+    DOTS_HIP(e2);
+    if (bad) {
+        set_error("front_setup: a pivot of the factorisation is not positive: K + (sigma + eps) M is not positive definite "
+                  "(disconnected mesh, degenerate triangles or eps < 0?)");
+        return DOTS_ERR_ARGUMENT;
+    }
     return 0;
 }
 

@@ -92,3 +92,4 @@ def test_time_pitches_64_128_and_ragged(T):
     for i in range(7):
         assert abs(got[i][0] - want[i]) <= 1e-7 * abs(want[i]) + 1e-14, (T, i)
     dev.close()
+
