@@ -27,7 +27,7 @@ EXPORTS = [
     "dots_sync", "dots_upload", "dots_download", "dots_array_count", "dots_step", "dots_run_phase", "dots_kkt",
     "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
-    "dots_step_begin", "dots_step_end", "dots_shard_elems", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags",
+    "dots_step_begin", "dots_step_end", "dots_shard_elems", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_stream_wait",
 ]
 
 
@@ -155,6 +155,7 @@ def load():
     lib.dots_front_enable.argtypes = [vp, C.c_int]
     lib.dots_front_pitch.argtypes = [vp]
     lib.dots_step_flags.argtypes = [vp, C.c_uint32]
+    lib.dots_stream_wait.argtypes = [vp, vp, C.c_int]
     lib.dots_device_bytes.argtypes = [vp]
     lib.dots_device_bytes.restype = C.c_int64
     for n in EXPORTS:

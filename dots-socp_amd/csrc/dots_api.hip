@@ -232,24 +232,32 @@ static int check(dots_ctx *ctx) {
 // first half of an iteration: right-hand side + solve (for this context's modes)
 static int run_iteration_begin(Ctx *c, dots_step_stats *st) {
     int rc;
+    if (!st) {   // enqueue only
+        if ((rc = launch_rhs(c))) return rc;
+        return cg_solve(c, nullptr);
+    }
     DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
     if ((rc = launch_rhs(c))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
     if ((rc = cg_solve(c, st))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
     DOTS_HIP(hipEventSynchronize(c->ev[2]));
-    if (st) {
-        float t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); st->ms_rhs += t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); st->ms_laplacian += t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[2])); st->ms_total += t;
-    }
+    float t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); st->ms_rhs += t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); st->ms_laplacian += t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[2])); st->ms_total += t;
     return 0;
 }
 
 // second half (sharded contexts): phi from the gathered mode-space solutions, then steps 1-2, 2 and 3
 static int run_iteration_end(Ctx *c, const double *gathered, dots_step_stats *st) {
     int rc;
+    if (!st) {   // enqueue only
+        if ((rc = cg_finish_sharded(c, gathered))) return rc;
+        if ((rc = launch_soc_projection(c, 1))) return rc;
+        c->zmid_stale = c->step_skip_zmid;
+        return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
+    }
     DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
     if ((rc = cg_finish_sharded(c, gathered))) return rc;
     if ((rc = launch_soc_projection(c, 1))) return rc;
@@ -258,13 +266,11 @@ static int run_iteration_end(Ctx *c, const double *gathered, dots_step_stats *st
     c->zmid_stale = c->step_skip_zmid;
     DOTS_HIP(hipEventRecord(c->ev[4], c->stream));
     DOTS_HIP(hipEventSynchronize(c->ev[4]));
-    if (st) {
-        float t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[3])); st->ms_soc += t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[3], c->ev[4])); st->ms_q_lambda_multiplier += t;
-        DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[4])); st->ms_total += t;
-        st->alm_iterations += 1;
-    }
+    float t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[3])); st->ms_soc += t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[3], c->ev[4])); st->ms_q_lambda_multiplier += t;
+    DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[4])); st->ms_total += t;
+    st->alm_iterations += 1;
     return 0;
 }
 
@@ -438,11 +444,13 @@ int dots_step_begin(dots_ctx *c, double *send, int64_t count, dots_step_stats *s
     if (!send || count != dots_shard_elems(c)) { set_error("step_begin: bad send buffer"); return DOTS_ERR_ARGUMENT; }
     dots_step_stats local;
     memset(&local, 0, sizeof local);
-    if ((rc = run_iteration_begin(c, &local))) return rc;
+    if ((rc = run_iteration_begin(c, stats ? &local : nullptr))) return rc;
     if (c->dcg.cg_ncol > 0) DOTS_HIP(hipMemcpyAsync(send, c->dcg.cg_x, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, c->stream));
     else DOTS_HIP(hipMemsetAsync(send, 0, sizeof(double) * (size_t)count, c->stream));
-    DOTS_HIP(hipStreamSynchronize(c->stream));
-    if (stats) *stats = local;
+    if (stats) {
+        DOTS_HIP(hipStreamSynchronize(c->stream));
+        *stats = local;
+    }
     return 0;
 }
 
@@ -455,8 +463,22 @@ int dots_step_end(dots_ctx *c, const double *recv, int64_t count, dots_step_stat
     if (!recv || count < n_ranks * elems || count % elems != 0) { set_error("step_end: bad receive buffer (need >= n_ranks chunks of shard_elems doubles)"); return DOTS_ERR_ARGUMENT; }
     dots_step_stats local;
     memset(&local, 0, sizeof local);
-    if ((rc = run_iteration_end(c, recv, &local))) return rc;
+    if ((rc = run_iteration_end(c, recv, stats ? &local : nullptr))) return rc;
     if (stats) *stats = local;
+    return 0;
+}
+
+int dots_stream_wait(dots_ctx *c, void *other_stream, int ctx_waits) {
+    int rc = check(c);
+    if (rc) return rc;
+    hipStream_t other = (hipStream_t)other_stream;       // nullptr = the legacy default stream
+    if (ctx_waits) {
+        DOTS_HIP(hipEventRecord(c->ev[10], other));
+        DOTS_HIP(hipStreamWaitEvent(c->stream, c->ev[10], 0));
+    } else {
+        DOTS_HIP(hipEventRecord(c->ev[11], c->stream));
+        DOTS_HIP(hipStreamWaitEvent(other, c->ev[11], 0));
+    }
     return 0;
 }
 

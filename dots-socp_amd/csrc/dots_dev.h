@@ -177,7 +177,7 @@ struct Ctx {
     int nnz = 0;
     int64_t bytes = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8]{};
+    hipEvent_t ev[12]{};
     double *stage = nullptr;      // device staging buffer (largest state array)
     int64_t stage_count = 0;
     double *h_pinned = nullptr;   // pinned host scalars

@@ -137,17 +137,22 @@ class DeviceProblem:
     def shard_elems(self):
         return int(self.lib.dots_shard_elems(self._h))
 
-    def step_begin(self, send_ptr, count):
-        """Right-hand side + PCG for this context's modes; the result is copied to device memory at send_ptr."""
-        st = _lib.StepStats()
-        _lib.check(self.lib.dots_step_begin(self._h, C.c_void_p(int(send_ptr)), int(count), C.byref(st)), "dots_step_begin")
+    def step_begin(self, send_ptr, count, wait=True):
+        """Right-hand side + solve for this context's modes; the result is copied to device memory at send_ptr.
+        ``wait=False``: only enqueue (order the exchange with ``stream_wait``); returns None."""
+        st = _lib.StepStats() if wait else None
+        _lib.check(self.lib.dots_step_begin(self._h, C.c_void_p(int(send_ptr)), int(count), C.byref(st) if wait else None), "dots_step_begin")
         return st
 
-    def step_end(self, recv_ptr, count):
+    def step_end(self, recv_ptr, count, wait=True):
         """Inverse time transform from the gathered buffer at recv_ptr, then steps 1-2, 2 and 3."""
-        st = _lib.StepStats()
-        _lib.check(self.lib.dots_step_end(self._h, C.c_void_p(int(recv_ptr)), int(count), C.byref(st)), "dots_step_end")
+        st = _lib.StepStats() if wait else None
+        _lib.check(self.lib.dots_step_end(self._h, C.c_void_p(int(recv_ptr)), int(count), C.byref(st) if wait else None), "dots_step_end")
         return st
+
+    def stream_wait(self, other_stream, ctx_waits):
+        """Order the context's stream against another HIP stream (an integer handle, 0 = default stream)."""
+        _lib.check(self.lib.dots_stream_wait(self._h, C.c_void_p(int(other_stream)), 1 if ctx_waits else 0), "dots_stream_wait")
 
     def run_phase(self, phase):
         st = _lib.StepStats()

@@ -57,18 +57,20 @@ class TorchComm:
         self.size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
 
-    def all_gather(self, recv, send):
+    def all_gather(self, recv, send, sync=True):
+        """``sync=False`` (device buffers): the result is only ordered on the current torch stream."""
         import torch
 
         if self.backend == "nccl":
             self.dist.all_gather_into_tensor(recv, send, group=self.group)
-            torch.cuda.current_stream().synchronize()
+            if sync:
+                torch.cuda.current_stream().synchronize()
         else:   # gloo: stage through the host
             h_send = send.detach().cpu()
             h_recv = torch.empty(recv.numel(), dtype=recv.dtype)
             self.dist.all_gather_into_tensor(h_recv, h_send, group=self.group)
             recv.copy_(h_recv.to(recv.device))
-            if recv.is_cuda:
+            if recv.is_cuda and sync:
                 torch.cuda.current_stream().synchronize()
 
     def any_flag(self, flag: bool) -> bool:
@@ -101,14 +103,14 @@ class ThreadComm:
         shared = cls._Shared(n)
         return [cls(shared, r) for r in range(n)]
 
-    def all_gather(self, recv, send):
+    def all_gather(self, recv, send, sync=True):
         import torch
 
         s = self.shared
         s.slots[self.rank] = send
-        s.barrier.wait()
+        s.barrier.wait()      # every rank has ordered the (shared) torch stream after its own context by now
         recv.copy_(torch.cat([x.reshape(-1) for x in s.slots]))
-        if recv.is_cuda:
+        if recv.is_cuda and sync:
             torch.cuda.synchronize()
         s.barrier.wait()
 
@@ -145,7 +147,20 @@ class ShardedAlmSolver(AlmSolver):
         self.comm_seconds = 0.0
 
     def _device_step(self, quiet=False):
+        import torch
+
         self.dev.step_flags(skip_z_mid=quiet)
+        on_device = self._send.is_cuda and self.direct
+        if on_device:
+            # no host wait anywhere: the context's stream and the stream the collective runs on are ordered by events
+            other = torch.cuda.current_stream(self._send.device).cuda_stream
+            self.dev.step_begin(self._send.data_ptr(), self._send.numel(), wait=False)
+            self.dev.stream_wait(other, ctx_waits=False)
+            self.comm.all_gather(self._recv, self._send, sync=False)
+            self.dev.stream_wait(other, ctx_waits=True)
+            self.dev.step_end(self._recv.data_ptr(), self._recv.numel(), wait=False)
+            self.untimed_steps += 1
+            return
         st1 = self.dev.step_begin(self._send.data_ptr(), self._send.numel())
         t0 = time.perf_counter()
         self.comm.all_gather(self._recv, self._send)

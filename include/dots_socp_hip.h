@@ -170,11 +170,17 @@ int dots_step_flags(dots_ctx *ctx, uint32_t flags);
  *   (caller)         all-gather of `send` over the ranks into `recv` = [n_ranks][V][pitch]  (RCCL)
  *   dots_step_end    inverse time transform from `recv`, then the cone projection and the
  *                    (q, lambda) + multiplier update
- * Both calls are synchronous with respect to the host (the context's stream is drained on return), so
- * the caller may hand the buffers to another stream/library.  Every rank holds the complete ALM state
- * (the element-wise steps are replicated, the solve is not): results are bit-identical on all ranks. */
+ * With stats != NULL both calls are synchronous with respect to the host (the context's stream is drained on
+ * return), so the caller may hand the buffers to another stream/library.  With stats == NULL they only enqueue
+ * on the context's stream; the caller orders the exchange against it with dots_stream_wait (no host wait at all:
+ * begin, wait(other <- ctx), all-gather on `other`, wait(ctx <- other), end).  Every rank holds the complete ALM
+ * state (the element-wise steps are replicated, the solve is not): results are bit-identical on all ranks. */
 int dots_step_begin(dots_ctx *ctx, double *send, int64_t count, dots_step_stats *stats);
 int dots_step_end(dots_ctx *ctx, const double *recv, int64_t count, dots_step_stats *stats);
+/* Stream ordering between the context's stream and another HIP stream of the same device (e.g. the one a
+ * communication library works on; NULL = the legacy default stream).  ctx_waits = 0: work enqueued on
+ * `other_stream` after the call waits for everything enqueued on the context so far; 1: the reverse. */
+int dots_stream_wait(dots_ctx *ctx, void *other_stream, int ctx_waits);
 int64_t dots_shard_elems(dots_ctx *ctx);   /* doubles one rank contributes: V * pitch;  -1 if not sharded */
 
 /* single phases of one iteration, for per-function parity tests */
