@@ -12,10 +12,12 @@
 //               y_p = L_pp^-1 w                    rows [0, n_p) of F_p (lower triangle only)
 //               u_p = (children's updates on bd_p) + G_p w          rows [n_p, n_p + b_p)
 //     backward  x_p = F_p^T [ y_p ; -x[bd_p] ]
-// Updates are PULLED by the parent from its children's buffers (pull0 / pull1 index maps), so nothing is
-// scattered and no atomics are needed: results are deterministic.  All nodes of one tree height are
-// independent: one launch per height and sweep, a workgroup = (node, block of rows | columns), the dot
-// products split over the workgroup's wave lanes that do not index the mode and folded through LDS.
+// Every child owns one plane of its parent's update buffer W (front-ordered, position map `cmap` precomputed from
+// the pull maps of the ABI): the child writes its update rows there, the parent reads its two planes contiguously.
+// No two writers share an address, so no atomics are needed and results are deterministic; entries no child
+// writes stay zero.  All nodes of one tree height are independent: one launch per height and sweep, a
+// workgroup = (node, block of rows | columns), the dot products split over the workgroup's lanes that do not
+// index the mode and folded by wave shuffles + LDS.
 // HBM-bound: one solve reads sum_p (n_p (n_p + 1) / 2 + b_p n_p) * modes * 8 bytes twice and touches the
 // vectors (V * modes * 8 bytes) a handful of times.
 #include "dots_dev.h"

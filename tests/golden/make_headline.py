@@ -1,0 +1,74 @@
+"""Record the headline runs of BASELINE.json's configurations (build container only; takes tens of minutes).
+
+    python tests/golden/make_headline.py reference sphere10k knot knot63     # the REFERENCE itself (via ref_shim)
+    python tests/golden/make_headline.py oracle torus100k                    # the CPU oracle (the reference would
+                                                                              # need hours at this size)
+
+Geometry comes from dots-socp_amd/meshes.py (deterministic generators), so a fixture stores
+only a checksum of it, the stopping iteration, the cost / objective / KKT histories and a sample of the solution
+(every 40th vertex of mu, plus per-layer sums and norms): ``headline_<workload>.npz``."""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from dots_socp_amd import meshes  # noqa: E402
+
+WORKLOADS = {   # same table as bench.py
+    "sphere10k": dict(example="sphere", kw=dict(level=5), n_time=31, congestion=0.0, tol=1e-3),
+    "knot": dict(example="knot", kw={}, n_time=31, congestion=0.0, tol=1e-3),
+    "knot63": dict(example="knot", kw={}, n_time=63, congestion=0.1, tol=1e-3),
+    "torus100k": dict(example="torus", kw=dict(nu=400, nv=250), n_time=31, congestion=0.0, tol=1e-3),
+}
+
+
+def main(argv):
+    who, names = argv[0], argv[1:]
+    if who == "reference":
+        import ref_shim
+        from make_golden import run_reference
+
+        ref = ref_shim.load_reference()
+        solve = lambda T, g, **kw: run_reference(ref, g, T, **kw)        # noqa: E731
+    else:
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("dots_oracle", os.path.join(ROOT, "oracle", "dots_oracle.py"))
+        O = importlib.util.module_from_spec(spec)
+        sys.modules["dots_oracle"] = O
+        spec.loader.exec_module(O)
+        solve = lambda T, g, **kw: O.solver_socp(T, g, **kw)              # noqa: E731
+    for name in names:
+        wl = WORKLOADS[name]
+        geom, scale = meshes.example(wl["example"], **wl["kw"])
+        t0 = time.time()
+        sol, hist = solve(wl["n_time"], geom, nit=20000, tol=wl["tol"], congestion=wl["congestion"])
+        sec = time.time() - t0
+        mu = np.asarray(sol["mu"])
+        out = dict(
+            source=np.array(who), n_time=np.array(wl["n_time"]), tol=np.array(wl["tol"]), congestion=np.array(wl["congestion"]),
+            scale_factor=np.array(scale), seconds=np.array(sec),
+            vertices_checksum=np.array([geom["vertices"].sum(), np.abs(geom["vertices"]).sum(), float(geom["triangles"].sum())]),
+            mu0_checksum=np.array([np.dot(geom["mu0"], np.arange(geom["mu0"].size)), np.dot(geom["mu1"], np.arange(geom["mu1"].size))]),
+            last_iteration=np.array(int(hist.kkt_iteration[-1])),
+            hist_kkt_errors=np.asarray(hist.kkt_errors, dtype=np.float64), hist_kkt_iteration=np.asarray(hist.kkt_iteration, dtype=np.float64),
+            mu_sample=mu[:, ::40].copy(), mu_layer_sum=mu.sum(axis=1), mu_layer_norm=np.sqrt((mu * mu).sum(axis=1)),
+            E_norm=np.array(np.sqrt((np.asarray(sol["E"]) ** 2).sum())), A_norm=np.array(np.sqrt((np.asarray(sol["A"]) ** 2).sum())),
+        )
+        for k, val in hist.history.items():
+            out["hist_" + k.replace(" ", "_")] = np.asarray(val, dtype=np.float64)
+        np.savez_compressed(os.path.join(HERE, f"headline_{name}.npz"), **out)
+        print("wrote", f"headline_{name}.npz", who, "last iteration", out["last_iteration"], "cost", hist.history["Transportation cost"][-1],
+              "seconds", round(sec, 1), flush=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
