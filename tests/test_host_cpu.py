@@ -255,3 +255,26 @@ def test_evaluate_helpers():
     rho = mu / w
     assert abs(d["l1"] - 1e-3 / (1.0 + np.sum(np.abs(rho) * w))) < 1e-15
     assert abs(d["linf"] - (1e-3 / w[7]) / (1.0 + rho.max())) < 1e-12
+
+
+def test_off_reader_round_trip_and_errors(tmp_path):
+    """meshes.read_off: contract of the reference's reader (data/util.py:73-144)."""
+    from dots_socp_amd import meshes
+
+    v, t = meshes.icosphere(1)
+    path = tmp_path / "ico.off"
+    meshes.write_off(path, v, t)
+    text = path.read_text().replace("\n3 ", "\n\n3 ", 1)        # an empty line is skipped
+    path.write_text(text)
+    v2, t2, e2 = meshes.read_off(str(path))
+    assert np.array_equal(v2, v) and np.array_equal(t2, t)
+    assert e2.shape == (3 * t.shape[0], 2)
+    assert np.array_equal(e2[:3], [[t[0, 0], t[0, 1]], [t[0, 1], t[0, 2]], [t[0, 2], t[0, 0]]])
+    g, _ = meshes.make_geometry(v2, t2)
+    assert g["vertices"].shape == v.shape
+    for bad in ("PLY\n1 0 0\n0 0 0\n", "OFF\n", "OFF\n2 1 0\n0 0 0\n3 0 0 0\n", "OFF\n1 2 0\n0 0 0\n3 0 0 0\n", "OFF\n1 0 0\n0 0\n"):
+        path.write_text(bad)
+        with pytest.raises(ValueError, match="Error reading .off file"):
+            meshes.read_off(str(path))
+    with pytest.raises(ValueError, match="Error reading .off file"):
+        meshes.read_off(str(tmp_path / "missing.off"))
