@@ -143,6 +143,17 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     if (p->lap_solver == DOTS_LAP_MODAL_PCG) {
         if (!p->time_modes || !p->time_eigs) { set_error("modal solver needs time_modes and time_eigs"); return DOTS_ERR_ARGUMENT; }
         UP(Q, p->time_modes, (d.T + 1) * (d.T + 1));
+        {
+            const int n = d.T + 1;
+            std::vector<double> qp((size_t)tp * tp, 0.0), qt((size_t)tp * tp, 0.0);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    qp[(size_t)i * tp + j] = p->time_modes[i * n + j];
+                    qt[(size_t)j * tp + i] = p->time_modes[i * n + j];
+                }
+            UP(Qpad, qp.data(), (int64_t)tp * tp);
+            UP(QpadT, qt.data(), (int64_t)tp * tp);
+        }
         std::vector<double> sig(tp, 0.0);
         for (int i = 0; i <= d.T; ++i) sig[i] = p->time_eigs[i];
         UP(sigma, sig.data(), tp);

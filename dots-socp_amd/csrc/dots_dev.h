@@ -59,6 +59,7 @@ struct Dev {
     const double *mu0, *mu1; // [V]
     const int *perm_v, *perm_f;
     const double *Q;         // [(T+1)^2] or null
+    const double *Qpad, *QpadT;  // [TP][TP] Q and its transpose, zero padded (operands of the MFMA transform)
     const double *sigma;     // [T+1] or null
     // state
     double *phi, *A, *B, *lam, *zf, *zm, *ze, *mu, *E, *bf, *bm, *be;
@@ -218,6 +219,8 @@ struct Ctx {
 };
 
 // The time-mode transforms stage a tile of rows and Q (in chunks of <= 32 KB) in LDS (k_time_modes_tile, k_rhs_modes)
+// T + 1 >= 64: the transforms are [V x (T+1)] x [(T+1) x (T+1)] fp64 GEMMs worth the matrix cores (k_time_modes_mfma)
+inline bool time_modes_mfma_ok(const Dev &d) { return d.TP >= 64 && d.TP <= 256 && d.Qpad != nullptr; }
 inline bool time_modes_tile_ok(const Dev &d) { return d.TP <= BLOCK && d.VT >= 1; }
 inline int time_modes_chunk(const Dev &d) { return (4096 / d.TP) < (d.T + 1) ? (4096 / d.TP) : (d.T + 1); }    // rows of Q per chunk
 inline size_t time_modes_tile_lds(const Dev &d) { return sizeof(double) * ((size_t)time_modes_chunk(d) * d.TP + (size_t)d.VT * (d.TP + 1)); }
@@ -267,6 +270,37 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double *lds /* [N*4] *
         for (int i = 0; i < N; ++i) v[i] = (lds[i * 4] + lds[i * 4 + 1]) + (lds[i * 4 + 2] + lds[i * 4 + 3]);
     }
 }
+// The same product on the matrix cores (T + 1 >= 64): one v_mfma_f64_16x16x4_f64 per 16 x 16 output tile and 4
+// values of i.  xs holds MROWS = 32 rows ([32][TP + 1], zero padded); wavefront w of the workgroup's NW takes the
+// (row tile, column tile) pairs w, w + NW, ...  Operand layout of the instruction (lane l), measured on gfx950
+// (profiles/micro/mfma_f64_layout.hip): A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16],
+// D[i = l / 16 + 4 r][j = l % 16] in the r-th accumulator register.
+// Qe = zero-padded Q (time -> modes) or Q^T (modes -> time), [TP][TP] row-major: no bounds checks in the loop.
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int TM_ROWS = 32;
+template <int NW>
+__device__ __forceinline__ void modes_from_tile_mfma(const Dev &d, const double *__restrict__ Qe, const double *xs, int v0, double *__restrict__ y) {
+    const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int n_jt = TP >> 4;                            // column tiles of 16
+    for (int tile = w; tile < 2 * n_jt; tile += NW) {
+        const int jt = tile % n_jt, vt = tile / n_jt;
+        mfma_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double *__restrict__ bq = Qe + (int64_t)lk * TP + jt * 16 + li;
+        const double *a = xs + (vt * 16 + li) * TPp + lk;
+        for (int k0 = 0; k0 < TP; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k0], bq[(int64_t)k0 * TP], acc, 0, 0, 0);
+        const int j = jt * 16 + li;
+        if (j < n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int v = v0 + vt * 16 + lk + 4 * r;
+                if (v < d.V) y[idxV(d, v, j)] = acc[r];
+            }
+        }
+    }
+}
+
 // y[v0 + vl][j] = sum_i Qeff[i][j] xs[vl][i] for the tile staged in xs ([VT][TP + 1], zero padded), with
 // Qeff[i][j] = Q[i][j] (FWD: time -> modes) or Q[j][i] (modes -> time), staged through Qs in chunks of IC rows.
 // A thread computes up to four outputs that share their Q column.  All threads of the workgroup must call it.

@@ -153,9 +153,25 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double ep
     modes_from_tile<true, RHS_NB>(d, d.Q, xs, Qs, IC, v0, bhat);
 }
 
+// T + 1 >= 64: 32 vertices per workgroup, the transform on the matrix cores.
+__global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, double eps, double *__restrict__ bhat) {
+    extern __shared__ double xs_m[];                    // [TM_ROWS][TP + 1]
+    const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+    const int v0 = blockIdx.x * TM_ROWS;
+    for (int e = threadIdx.x; e < TM_ROWS * TP; e += RHS_NB) {
+        const int vl = e >> d.tp_shift, t = e & (TP - 1);
+        xs_m[vl * TPp + t] = (v0 + vl < d.V && t < n) ? rhs_value(d, v0 + vl, t, r, eps) : 0.0;
+    }
+    __syncthreads();
+    modes_from_tile_mfma<RHS_NB / 64>(d, d.Qpad, xs_m, v0, bhat);
+}
+
 int launch_rhs(Ctx *c) {
     const int g = xcd_grid(c->d.n_vtiles);
-    if (rhs_writes_modes(c))
+    if (rhs_writes_modes(c) && time_modes_mfma_ok(c->d))
+        hipLaunchKernelGGL(k_rhs_modes_mfma, dim3((c->d.V + TM_ROWS - 1) / TM_ROWS), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
+                           c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0);
+    else if (rhs_writes_modes(c))
         hipLaunchKernelGGL(k_rhs_modes, dim3(g), dim3(RHS_NB), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps,
                            c->d.cg_p0, time_modes_chunk(c->d));
     else

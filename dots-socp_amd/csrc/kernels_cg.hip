@@ -444,6 +444,20 @@ __global__ __launch_bounds__(BLOCK) void k_time_modes_tile(Dev d, const double *
     modes_from_tile<FWD>(d, d.Q, xs, Qs, IC, v0, y);
 }
 
+// The transform as a GEMM on the matrix cores (T + 1 >= 64; modes_from_tile_mfma in dots_dev.h): a workgroup
+// stages the rows of 32 vertices in LDS, its four wavefronts split the 16 x 16 output tiles.
+__global__ __launch_bounds__(BLOCK) void k_time_modes_mfma(Dev d, const double *__restrict__ Qe, const double *__restrict__ x, double *__restrict__ y) {
+    extern __shared__ double xs_m[];                    // [TM_ROWS][TP + 1]
+    const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+    const int v0 = blockIdx.x * TM_ROWS;
+    for (int e = threadIdx.x; e < TM_ROWS * TP; e += BLOCK) {
+        const int vl = e >> d.tp_shift, t = e & (TP - 1);
+        xs_m[vl * TPp + t] = (v0 + vl < d.V && t < n) ? x[idxV(d, v0 + vl, t)] : 0.0;
+    }
+    __syncthreads();
+    modes_from_tile_mfma<BLOCK / 64>(d, Qe, xs_m, v0, y);
+}
+
 // ------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------
@@ -718,7 +732,10 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
     }
     if (rc) return rc;
     if (MODAL && !sharded) {
-        if (time_modes_tile_ok(d))
+        if (time_modes_mfma_ok(d))
+            hipLaunchKernelGGL(k_time_modes_mfma, dim3((d.V + TM_ROWS - 1) / TM_ROWS), dim3(BLOCK), sizeof(double) * TM_ROWS * (d.TP + 1), c->stream, d, d.QpadT,
+                               d.cg_x, d.phi);
+        else if (time_modes_tile_ok(d))
             hipLaunchKernelGGL((k_time_modes_tile<false>), dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, d.cg_x, d.phi, time_modes_chunk(d));
         else
             hipLaunchKernelGGL((k_time_modes<false>), dim3(gt), dim3(BLOCK), 0, c->stream, d, d.cg_x, d.phi, 0);
