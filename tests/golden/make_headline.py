@@ -50,7 +50,7 @@ def main(argv):
         wl = WORKLOADS[name]
         geom, scale = meshes.example(wl["example"], **wl["kw"])
         t0 = time.time()
-        sol, hist = solve(wl["n_time"], geom, nit=20000, tol=wl["tol"], congestion=wl["congestion"])
+        sol, hist = solve(wl["n_time"], geom, nit=20000, tol=wl["tol"], congestion=wl["congestion"], time_limit=1e9)
         sec = time.time() - t0
         mu = np.asarray(sol["mu"])
         out = dict(

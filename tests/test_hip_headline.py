@@ -33,7 +33,7 @@ def test_headline_configuration(path):
     chk = np.array([geom["vertices"].sum(), np.abs(geom["vertices"]).sum(), float(geom["triangles"].sum())])
     assert np.allclose(chk, g["vertices_checksum"], rtol=1e-13)
     assert abs(scale - float(g["scale_factor"])) < 1e-14
-    sol, hist = solver_socp(int(g["n_time"]), geom, nit=20000, tol=float(g["tol"]), congestion=float(g["congestion"]))
+    sol, hist = solver_socp(int(g["n_time"]), geom, nit=20000, tol=float(g["tol"]), congestion=float(g["congestion"]), time_limit=1e9)
     assert int(hist.kkt_iteration[-1]) == int(g["last_iteration"])
     want, got = g["hist_kkt_errors"], hist.kkt_errors
     assert got.shape == want.shape
