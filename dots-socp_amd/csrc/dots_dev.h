@@ -109,6 +109,13 @@ struct FrontNode {
     int64_t ioff;             // first front row in the pull maps
     int64_t soff;             // first entry of the b x b Schur complement
 };
+// One workgroup of a sweep: the node's record and the first row (column) of its block, in ONE 96-byte record so
+// that the kernel's dependent-load chain starts with a single (scalar) load instead of descriptor -> node record.
+struct FrontWork {
+    FrontNode nd;
+    int first;
+    int pad;
+};
 struct FrontDev {
     int n_nodes = 0, n_levels = 0;
     const FrontNode *nodes = nullptr;
@@ -117,7 +124,7 @@ struct FrontDev {
     const int *cmap = nullptr;            // position of every boundary row in the parent's front
     const double *F = nullptr;
     double *W = nullptr;                  // update planes [rows][TP]; entries no child writes stay zero
-    const int2 *fwd_desc = nullptr, *bwd_desc = nullptr;                  // (node, first row / first column) per workgroup
+    const FrontWork *fwd_desc = nullptr, *bwd_desc = nullptr;             // per workgroup: node record + first row / first column
 };
 
 // Layout of the device scalar block used by the PCG (all arrays have NC entries, NC <= 256).

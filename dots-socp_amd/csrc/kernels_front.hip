@@ -74,12 +74,12 @@ __device__ __forceinline__ double front_folded(const double *red, int r, int TP,
 // is stored as zeros), so that the compiler issues the RB + 3 loads of a step back to back and waits once.
 // RB is the level's exact block size (1, 2 or 4: no duplicate loads); LEAF (tree height 0): no update planes to read.
 template <int NB, int RB, bool VMAP, bool LEAF>
-__global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const int2 *__restrict__ desc, int rb, const double *__restrict__ bhat,
+__global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const FrontWork *__restrict__ desc, int rb, const double *__restrict__ bhat,
                                                   double *__restrict__ Y) {
     __shared__ double red[RB * (NB / 64) * 64];
-    const int2 ds = desc[blockIdx.x];
-    const FrontNode nd = f.nodes[ds.x];
-    const int row0 = ds.y;
+    const FrontWork wk = desc[blockIdx.x];
+    const FrontNode &nd = wk.nd;
+    const int row0 = wk.first;
     const int sh = g.sh, tid = threadIdx.x;
     const int a = tid & (g.TP - 1), q = tid >> sh, Q = NB >> sh;
     const int n = nd.n, m = n + nd.b;
@@ -96,6 +96,8 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
         acc[r] = 0.0;
         rowp[r] = Fp + (((int64_t)(r < nr ? row0 + r : row0) * n) << sh);
     }
+    // where this thread's (first) update row goes in the parent's plane: loaded now, needed after the fold
+    const int cm0 = (q < nr && row0 + q >= n) ? f.cmap[nd.bdoff + (row0 + q - n)] : 0;
     // rows of L^-1 only need the columns j <= i: the block's last row bounds the loop
     const int last = row0 + nr - 1;
     const int jmax = last < n ? last + 1 : n;
@@ -121,19 +123,20 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
             Y[(front_row(f, nd.k0 + i) << sh) + a] = s;
         } else {   // update row: carry the children's contributions on, hand the sum to the parent's plane
             if (!LEAF) s += W0[(int64_t)i << sh] + W0[plane + ((int64_t)i << sh)];
-            f.W[((nd.parent_w + f.cmap[nd.bdoff + (i - n)]) << sh) + a] = s;
+            const int cm = r == q ? cm0 : f.cmap[nd.bdoff + (i - n)];
+            f.W[((nd.parent_w + cm) << sh) + a] = s;
         }
     }
 }
 
 // backward sweep of one tree height.  Workgroup = (node, cb <= RB columns).  Same load discipline.
 template <int NB, int RB, bool VMAP>
-__global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const int2 *__restrict__ desc, int cb, const double *__restrict__ Y,
+__global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const FrontWork *__restrict__ desc, int cb, const double *__restrict__ Y,
                                                   double *X) {
     __shared__ double red[RB * (NB / 64) * 64];
-    const int2 ds = desc[blockIdx.x];
-    const FrontNode nd = f.nodes[ds.x];
-    const int col0 = ds.y;
+    const FrontWork wk = desc[blockIdx.x];
+    const FrontNode &nd = wk.nd;
+    const int col0 = wk.first;
     const int sh = g.sh, tid = threadIdx.x;
     const int a = tid & (g.TP - 1), q = tid >> sh, Q = NB >> sh;
     const int n = nd.n, m = n + nd.b;
@@ -331,7 +334,13 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     // ---- workgroup lists: (node, first row) per level for the forward sweep, (node, first column) backward.
     // Levels with many rows: 256-thread workgroups of up to 4 rows; the few large nodes near the root: one row
     // per 1024-thread workgroup, so that the long dot products are split 4x finer.
-    std::vector<int2> fwd, bwd;
+    std::vector<FrontWork> fwd, bwd;
+    auto work = [&](int p, int first) {
+        FrontWork w{};
+        w.nd = nodes[(size_t)p];
+        w.first = first;
+        return w;
+    };
     for (int l = 0; l < h->n_levels; ++l) {
         int64_t rows = 0, cols = 0;
         for (int k = h->level_ptr[l]; k < h->level_ptr[l + 1]; ++k) {
@@ -356,8 +365,8 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         c->front_bwd_ptr[l] = (int)bwd.size();
         for (int k = h->level_ptr[l]; k < h->level_ptr[l + 1]; ++k) {
             const int p = h->level_nodes[k];
-            for (int r = 0; r < h->node_n[p] + h->node_b[p]; r += rb) fwd.push_back(make_int2(p, r));
-            for (int r = 0; r < h->node_n[p]; r += cb) bwd.push_back(make_int2(p, r));
+            for (int r = 0; r < h->node_n[p] + h->node_b[p]; r += rb) fwd.push_back(work(p, r));
+            for (int r = 0; r < h->node_n[p]; r += cb) bwd.push_back(work(p, r));
         }
     }
     c->front_fwd_ptr[h->n_levels] = (int)fwd.size();
@@ -411,7 +420,7 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
     for (int l = 0; l < f.n_levels; ++l) {
         const int n = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
         if (n <= 0) continue;
-        const int2 *ptr = f.fwd_desc + c->front_fwd_ptr[l];
+        const FrontWork *ptr = f.fwd_desc + c->front_fwd_ptr[l];
         const int blk = c->front_fwd_rb[l];
         const bool big = c->front_fwd_nb[l] == 1024;
         if (l == 0) {            // height 0: leaves only
@@ -425,7 +434,7 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
     for (int l = f.n_levels - 1; l >= 0; --l) {
         const int n = c->front_bwd_ptr[l + 1] - c->front_bwd_ptr[l];
         if (n <= 0) continue;
-        const int2 *ptr = f.bwd_desc + c->front_bwd_ptr[l];
+        const FrontWork *ptr = f.bwd_desc + c->front_bwd_ptr[l];
         const int blk = c->front_bwd_cb[l];
         if (c->front_bwd_nb[l] == 1024) { if (blk == 1) FRONT_BWD(1024, 1); else if (blk == 2) FRONT_BWD(1024, 2); else FRONT_BWD(1024, 4); }
         else { if (blk == 1) FRONT_BWD(256, 1); else if (blk == 2) FRONT_BWD(256, 2); else FRONT_BWD(256, 4); }
