@@ -93,3 +93,21 @@ def test_time_pitches_64_128_and_ragged(T):
         assert abs(got[i][0] - want[i]) <= 1e-7 * abs(want[i]) + 1e-14, (T, i)
     dev.close()
 
+
+
+@pytest.mark.parametrize("T,prec", [(63, "jacobi"), (63, "multigrid"), (127, "jacobi")])
+def test_pcg_alternatives_at_large_time_pitch(T, prec):
+    """The PCG solvers at time pitch 64 / 128 give the direct solver's phi."""
+    geom, _ = meshes.example("sphere", level=2)
+    out = {}
+    for tag in ("direct", "pcg"):
+        dev = make(geom, T, 1e-3, "nd" if tag == "direct" else True)
+        if tag == "direct":
+            dev.setup_frontal(eps=1e-3)
+        elif prec == "multigrid":
+            assert dev.setup_multigrid(eps=1e-3, coarsest=12) is not None
+        st = dev.run_phase("laplacian")
+        assert st.cg_not_converged == 0
+        out[tag] = dev.download("phi")
+        dev.close()
+    assert rel(out["pcg"], out["direct"]) < 1e-8
