@@ -146,3 +146,31 @@ def test_plane_against_the_exact_transport():
     assert err["l1"] < 1e-2 and err["l2"] < 1e-2 and err["linf"] < 5e-2
     assert evaluate.check_mass_conservation(sol["mu"])[0] < 1e-4
     assert evaluate.check_negative_mass(sol["mu"])[0] < 1e-5
+
+
+@pytest.mark.parametrize("case", ["one_triangle_T1", "two_triangles_T2", "tetrahedron_T3"])
+def test_smallest_problems_match_the_oracle(case):
+    """Edge sizes: a single triangle with one time interval, a two-triangle strip, a closed tetrahedron."""
+    from dots_socp_amd.socp import solver_socp
+
+    if case == "one_triangle_T1":
+        v = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.2, 0.9, 0.0]])
+        t, T = np.array([[0, 1, 2]]), 1
+    elif case == "two_triangles_T2":
+        v = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.1, 0.8, 0.0], [1.1, 0.9, 0.3]])
+        t, T = np.array([[0, 1, 2], [1, 3, 2]]), 2
+    else:
+        v = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.5, 0.9, 0.0], [0.5, 0.3, 0.8]])
+        t, T = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [2, 0, 3]]), 3
+    n = v.shape[0]
+    mu0 = np.arange(1.0, n + 1.0)
+    mu1 = mu0[::-1].copy()
+    geom = dict(vertices=v, triangles=t, mu0=mu0 / mu0.sum(), mu1=mu1 / mu1.sum())
+    kw = dict(nit=40, tol=1e-9, check_kkt_step_by_step=True)
+    sol, hist = solver_socp(T, geom, **kw)
+    ref_sol, ref_hist = O.solver_socp(T, geom, **kw)
+    assert hist.kkt_errors.shape == ref_hist.kkt_errors.shape
+    assert np.allclose(hist.kkt_errors, ref_hist.kkt_errors, rtol=1e-6, atol=1e-12)
+    assert np.allclose(hist.history["Transportation cost"], ref_hist.history["Transportation cost"], rtol=1e-6, atol=1e-14)
+    for k in ("mu", "E", "A", "B"):
+        assert rel(sol[k], ref_sol[k]) < 1e-6, k
