@@ -245,37 +245,49 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
         const int row = row0 + (e >> d.tp_shift), t = e & (d.TP - 1);
         if (row >= 3 * d.F || t > d.T) continue;
         const int f = row / 3, c = row - 3 * f;
-        double gx = 0.0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gx += d.hat[(f * 3 + k) * 3 + c] * d.phi[idxV(d, d.tri[f * 3 + k], t)];
-        double z0[3], b0[3], z1[3], b1[3];
-        double S = 0.0;
+        // All loads first and unconditional (intervals past the ends are clamped to a valid one and masked
+        // afterwards): the compiler then issues them back to back instead of one wait per guarded load.
+        const bool has0 = t < d.T, has1 = t > 0;
+        const int t0 = has0 ? t : t - 1, t1 = has1 ? t - 1 : t;      // T >= 1: both are valid interval indices
         const int64_t ie = idxF(d, f, c, t);
-        const double sBold = ZMODE ? sB * d.B[ie] : 0.0;   // both pre-images of this thread's corners use B_old at ITS node
+        int vk[3];
+        double hk[3], Dk[3], phik[3], l0[3], l1[3], b0[3], b1[3], z0[3], z1[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            z0[k] = b0[k] = z1[k] = b1[k] = 0.0;
-            const double D = ZMODE ? d.fk_D[f * 3 + k] : 1.0;
-            const int ivk = ZMODE ? idxV(d, d.tri[f * 3 + k], t) : 0;
-            if (t < d.T) {
-                const int64_t i = idxM(d, f * 3 + k, 0, c, t);
-                b0[k] = d.bm[i];
-                if (ZMODE) {
-                    z0[k] = (d.lamc[ivk] / D) * (D * (sBold - b0[k]));
-                    if (ZMODE == 1) d.zm[i] = z0[k];
-                } else {
-                    z0[k] = d.zm[i];
-                }
+            vk[k] = d.tri[f * 3 + k];
+            hk[k] = d.hat[(f * 3 + k) * 3 + c];
+            Dk[k] = ZMODE ? d.fk_D[f * 3 + k] : 1.0;
+        }
+        const double Bold = ZMODE ? d.B[ie] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            phik[k] = d.phi[idxV(d, vk[k], t)];
+            b0[k] = d.bm[idxM(d, f * 3 + k, 0, c, t0)];
+            b1[k] = d.bm[idxM(d, f * 3 + k, 1, c, t1)];
+            if (ZMODE) {
+                l0[k] = d.lamc[idxV(d, vk[k], t0)];
+                l1[k] = d.lamc[idxV(d, vk[k], t1)];
+            } else {
+                z0[k] = d.zm[idxM(d, f * 3 + k, 0, c, t0)];
+                z1[k] = d.zm[idxM(d, f * 3 + k, 1, c, t1)];
             }
-            if (t > 0) {
-                const int64_t i = idxM(d, f * 3 + k, 1, c, t - 1);
-                b1[k] = d.bm[i];
-                if (ZMODE) {
-                    z1[k] = (d.lamc[ivk - 1] / D) * (D * (sBold - b1[k]));
-                    if (ZMODE == 1) d.zm[i] = z1[k];
-                } else {
-                    z1[k] = d.zm[i];
-                }
+        }
+        double gx = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gx += hk[k] * phik[k];
+        double S = 0.0;
+        const double sBold = sB * Bold;   // both pre-images of this thread's corners use B_old at ITS node
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (ZMODE) {
+                z0[k] = (l0[k] / Dk[k]) * (Dk[k] * (sBold - b0[k]));
+                z1[k] = (l1[k] / Dk[k]) * (Dk[k] * (sBold - b1[k]));
+            }
+            if (!has0) z0[k] = b0[k] = 0.0;
+            if (!has1) z1[k] = b1[k] = 0.0;
+            if (ZMODE == 1) {
+                if (has0) d.zm[idxM(d, f * 3 + k, 0, c, t)] = z0[k];
+                if (has1) d.zm[idxM(d, f * 3 + k, 1, c, t - 1)] = z1[k];
             }
             S += (z0[k] + b0[k]) + (z1[k] + b1[k]);
         }
