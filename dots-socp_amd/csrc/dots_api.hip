@@ -288,18 +288,20 @@ static int run_iteration_end(Ctx *c, const double *gathered, dots_step_stats *st
 static int run_iteration(Ctx *c, dots_step_stats *st) {
     int rc;
     if (!st) {   // asynchronous: enqueue only (the direct solver needs no host round trip); nothing is timed
+        const bool fuse = soc_takes_inverse(c);
         if ((rc = launch_rhs(c))) return rc;
-        if ((rc = cg_solve(c, nullptr))) return rc;
-        if ((rc = launch_soc_projection(c, 1))) return rc;
+        if ((rc = cg_solve(c, nullptr, fuse))) return rc;
+        if ((rc = launch_soc_projection(c, 1, fuse))) return rc;
         c->zmid_stale = c->step_skip_zmid;
         return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
     }
     DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
     if ((rc = launch_rhs(c))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
-    if ((rc = cg_solve(c, st))) return rc;
+    const bool fuse = soc_takes_inverse(c);
+    if ((rc = cg_solve(c, st, fuse))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
-    if ((rc = launch_soc_projection(c, 1))) return rc;
+    if ((rc = launch_soc_projection(c, 1, fuse))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[3], c->stream));
     if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
     c->zmid_stale = c->step_skip_zmid;

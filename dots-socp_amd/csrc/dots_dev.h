@@ -146,7 +146,7 @@ constexpr int FLAG_TOTAL = CgScalOffsets::NCMAX + 8;
 struct Ctx;
 
 // ---- launch wrappers implemented in the kernel files (all asynchronous on ctx stream) ----
-int launch_soc_projection(Ctx *c, int zmid_mode = 0);   // 0: write z_mid; 1: write only the cone multiplier
+int launch_soc_projection(Ctx *c, int zmid_mode = 0, bool with_inverse = false);   // 0: write z_mid; 1: write only the cone multiplier; with_inverse: extra workgroups do the modes -> time transform of phi
 int launch_rhs(Ctx *c);
 int launch_q_lambda_mult(Ctx *c, int zmid_mode = 0);    // 0: read z_mid; 1: rebuild it from the multiplier and store it; 2: rebuild, do not store
 int launch_adjust_penalty(Ctx *c, double factor);
@@ -156,7 +156,7 @@ int launch_to_device_layout(Ctx *c, int array_id, const double *staged);
 int launch_from_device_layout(Ctx *c, int array_id, double *staged);
 int launch_operator(Ctx *c, int op, double scale, const double *in_staged, double *out_staged);
 int launch_calibration(Ctx *c, double *bytes_each_way);
-int cg_solve(Ctx *c, dots_step_stats *stats);
+int cg_solve(Ctx *c, dots_step_stats *stats, bool defer_inverse = false);   // defer_inverse: phi is produced by the caller (soc_takes_inverse)
 int cg_apply_operator(Ctx *c, const double *x_node, double *y_node);  // y = K x in node layout
 int cg_finish_sharded(Ctx *c, const double *gathered);                // phi from all ranks' mode-space solutions
 int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes);
@@ -231,10 +231,15 @@ inline bool time_modes_mfma_ok(const Dev &d) { return d.TP >= 64 && d.TP <= 256 
 inline bool time_modes_tile_ok(const Dev &d) { return d.TP <= BLOCK && d.VT >= 1; }
 inline int time_modes_chunk(const Dev &d) { return (4096 / d.TP) < (d.T + 1) ? (4096 / d.TP) : (d.T + 1); }    // rows of Q per chunk
 inline size_t time_modes_tile_lds(const Dev &d) { return sizeof(double) * ((size_t)time_modes_chunk(d) * d.TP + (size_t)d.VT * (d.TP + 1)); }
+// direct solver on one GPU, T + 1 < 64: the inverse time transform of phi rides in the cone-projection launch (the
+// projection reads neither phi nor anything the solve writes: steps 1-1 and 1-2 are a separable block)
+inline bool soc_takes_inverse(const Ctx *c);
 // direct solver on one GPU: the right-hand-side kernel writes the mode-space right-hand side itself
 inline bool rhs_writes_modes(const Ctx *c) {
     return c->use_front && c->front.n_nodes > 0 && c->shard_stride == 0 && c->lap_solver == DOTS_LAP_MODAL_PCG && time_modes_tile_ok(c->d);
 }
+
+inline bool soc_takes_inverse(const Ctx *c) { return rhs_writes_modes(c) && !time_modes_mfma_ok(c->d); }
 
 int64_t array_count_host(const Dev &d, int array_id);    // elements in the reference layout
 int64_t array_count_device(const Dev &d, int array_id);  // elements in the device layout

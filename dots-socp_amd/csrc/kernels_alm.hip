@@ -19,11 +19,26 @@ namespace dots {
 // the fly from beta_mid and B, which they read anyway: the second corner walk and 18*T*F stores disappear here,
 // 18*T*F loads disappear there.
 template <bool ONLY_MULTIPLIER>
-__global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, double cd) {
+__global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, double cd, int n_soc, int IC) {
+    // Workgroups [n_soc, gridDim.x): the modes -> time transform of phi (independent of the projection, same launch)
+    if ((int)blockIdx.x >= n_soc) {
+        extern __shared__ double tm_lds[];
+        const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+        double *Qs = tm_lds, *xs = tm_lds + IC * TP;
+        const int tile = xcd_tile(blockIdx.x - n_soc, d.n_vtiles);
+        if (tile >= d.n_vtiles) return;
+        const int v0 = tile * d.VT;
+        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+            const int vl = e >> d.tp_shift, t = e & (TP - 1);
+            xs[vl * TPp + t] = (v0 + vl < d.V && t < n) ? d.cg_x[idxV(d, v0 + vl, t)] : 0.0;
+        }
+        modes_from_tile<false>(d, d.Q, xs, Qs, IC, v0, d.phi);
+        return;
+    }
     // one element per thread: a workgroup takes a quarter of a tile (the corner walk is a chain of dependent
     // loads; four elements per thread would serialise four of them)
     // (block b and block b + G8 share a tile and an XCD: G8 is a multiple of 8)
-    const int G8 = gridDim.x / (TILE_ELEMS / BLOCK);
+    const int G8 = n_soc / (TILE_ELEMS / BLOCK);
     const int tile = xcd_tile(blockIdx.x % G8, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
     const int v0 = tile * d.VT;
@@ -74,13 +89,15 @@ __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, doub
     }
 }
 
-int launch_soc_projection(Ctx *c, int zmid_mode) {
+int launch_soc_projection(Ctx *c, int zmid_mode, bool with_inverse) {
+    const int n_soc = xcd_grid(c->d.n_vtiles) * (TILE_ELEMS / BLOCK);
+    const int n_inv = with_inverse ? xcd_grid(c->d.n_vtiles) : 0;
+    const size_t lds = with_inverse ? time_modes_tile_lds(c->d) : 0;
+    const int IC = time_modes_chunk(c->d);
     if (zmid_mode)
-        hipLaunchKernelGGL((k_soc_projection<true>), dim3(xcd_grid(c->d.n_vtiles) * (TILE_ELEMS / BLOCK)), dim3(BLOCK), 0, c->stream, c->d,
-                           c->prm.scale_z, c->prm.const_d);
+        hipLaunchKernelGGL((k_soc_projection<true>), dim3(n_soc + n_inv), dim3(BLOCK), lds, c->stream, c->d, c->prm.scale_z, c->prm.const_d, n_soc, IC);
     else
-        hipLaunchKernelGGL((k_soc_projection<false>), dim3(xcd_grid(c->d.n_vtiles) * (TILE_ELEMS / BLOCK)), dim3(BLOCK), 0, c->stream, c->d,
-                           c->prm.scale_z, c->prm.const_d);
+        hipLaunchKernelGGL((k_soc_projection<false>), dim3(n_soc + n_inv), dim3(BLOCK), lds, c->stream, c->d, c->prm.scale_z, c->prm.const_d, n_soc, IC);
     DOTS_HIP(hipGetLastError());
     return 0;
 }

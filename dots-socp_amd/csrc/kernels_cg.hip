@@ -687,7 +687,7 @@ __global__ __launch_bounds__(BLOCK) void k_time_modes_inv_gathered(Dev d, const 
 // Step 1 for the modes of this context.  Unsharded: also transforms back (phi is complete on return).
 // Sharded: the local mode-space solution stays in dcg.cg_x for the caller to exchange (cg_finish_sharded).
 template <bool MODAL>
-static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
+static int cg_solve_impl(Ctx *c, dots_step_stats *stats, bool defer_inverse) {
     const Dev &d = c->d;
     const Dev &g = c->dcg;
     const int gt = xcd_grid(d.n_vtiles);
@@ -731,7 +731,7 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
         rc = cg_core<MODAL>(c, b, x, stats);
     }
     if (rc) return rc;
-    if (MODAL && !sharded) {
+    if (MODAL && !sharded && !defer_inverse) {
         if (time_modes_mfma_ok(d))
             hipLaunchKernelGGL(k_time_modes_mfma, dim3((d.V + TM_ROWS - 1) / TM_ROWS), dim3(BLOCK), sizeof(double) * TM_ROWS * (d.TP + 1), c->stream, d, d.QpadT,
                                d.cg_x, d.phi);
@@ -744,8 +744,8 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats) {
     return 0;
 }
 
-int cg_solve(Ctx *c, dots_step_stats *stats) {
-    return c->lap_solver == DOTS_LAP_MODAL_PCG ? cg_solve_impl<true>(c, stats) : cg_solve_impl<false>(c, stats);
+int cg_solve(Ctx *c, dots_step_stats *stats, bool defer_inverse) {
+    return c->lap_solver == DOTS_LAP_MODAL_PCG ? cg_solve_impl<true>(c, stats, defer_inverse) : cg_solve_impl<false>(c, stats, false);
 }
 
 // phi from the mode-space solutions of all ranks (device buffer [n_ranks][V][local pitch])
