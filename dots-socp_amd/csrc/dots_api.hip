@@ -288,11 +288,16 @@ static int run_iteration_end(Ctx *c, const double *gathered, dots_step_stats *st
 static int run_iteration(Ctx *c, dots_step_stats *st) {
     int rc;
     if (!st) {   // asynchronous: enqueue only (the direct solver needs no host round trip); nothing is timed
+        c->zmid_stale = c->step_skip_zmid;
+        if (rhs_takes_soc(c)) {   // [right-hand side + projection] -> sweeps -> inverse transform -> steps 2+3
+            if ((rc = launch_rhs(c, true))) return rc;
+            if ((rc = cg_solve(c, nullptr))) return rc;
+            return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
+        }
         const bool fuse = soc_takes_inverse(c);
         if ((rc = launch_rhs(c))) return rc;
         if ((rc = cg_solve(c, nullptr, fuse))) return rc;
         if ((rc = launch_soc_projection(c, 1, fuse))) return rc;
-        c->zmid_stale = c->step_skip_zmid;
         return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
     }
     DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
@@ -373,6 +378,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
     c->device = desc->device;
     if (const char *e = getenv("DOTS_CG_STAGE_LDS")) c->cg_stage_lds = atoi(e) != 0;
     if (const char *e = getenv("DOTS_MG_TAIL_ROWS")) c->mg_tail_rows = atoi(e);
+    if (const char *e = getenv("DOTS_SOC_WITH_RHS")) c->soc_with_rhs = atoi(e) != 0;
     if (const char *e = getenv("DOTS_FRONT_RB")) c->front_rb_max = std::min(4, std::max(1, atoi(e)));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }

@@ -147,7 +147,7 @@ struct Ctx;
 
 // ---- launch wrappers implemented in the kernel files (all asynchronous on ctx stream) ----
 int launch_soc_projection(Ctx *c, int zmid_mode = 0, bool with_inverse = false);   // 0: write z_mid; 1: write only the cone multiplier; with_inverse: extra workgroups do the modes -> time transform of phi
-int launch_rhs(Ctx *c);
+int launch_rhs(Ctx *c, bool with_soc = false);   // with_soc (only when rhs_takes_soc): the cone projection rides in the same launch
 int launch_q_lambda_mult(Ctx *c, int zmid_mode = 0);    // 0: read z_mid; 1: rebuild it from the multiplier and store it; 2: rebuild, do not store
 int launch_adjust_penalty(Ctx *c, double factor);
 int launch_scale_z(Ctx *c, double z_mul, double beta_mul, double sz_new);
@@ -197,6 +197,7 @@ struct Ctx {
     int use_mg = 1;
     int mg_tail_rows = 256;       // levels with at most this many rows run inside the single tail launch (DOTS_MG_TAIL_ROWS)
     int cg_graph_mg = -1;
+    int soc_with_rhs = 1;         // DOTS_SOC_WITH_RHS=0: keep the projection after the solve (A/B measurements)
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
     int zmid_stale = 0;           // z_mid does not belong to the current iterate
     FrontDev front{};             // multifrontal factor (n_nodes == 0: none)
@@ -240,6 +241,8 @@ inline bool rhs_writes_modes(const Ctx *c) {
 }
 
 inline bool soc_takes_inverse(const Ctx *c) { return rhs_writes_modes(c) && !time_modes_mfma_ok(c->d); }
+// ... or the projection itself rides in the right-hand-side launch (enqueue-only iterations; TILE_ELEMS threads per tile)
+inline bool rhs_takes_soc(const Ctx *c) { return c->soc_with_rhs && rhs_writes_modes(c) && !time_modes_mfma_ok(c->d); }
 
 int64_t array_count_host(const Dev &d, int array_id);    // elements in the reference layout
 int64_t array_count_device(const Dev &d, int array_id);  // elements in the device layout

@@ -19,6 +19,51 @@ namespace dots {
 // the fly from beta_mid and B, which they read anyway: the second corner walk and 18*T*F stores disappear here,
 // 18*T*F loads disappear there.
 template <bool ONLY_MULTIPLIER>
+__device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double sz, double cd) {
+    const double sB = sz * INV_SQRT3;
+    const int iv = idxV(d, v, t);
+    const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
+    double acc = 0.0;
+    for (int j = j0; j < j1; ++j) {
+        const int fk = d.cidx[j];
+        const int f = fk / 3;
+        const double D = d.c_D[j];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double w = D * (sB * d.B[idxF(d, f, c, t + s)] - d.bm[idxM(d, fk, s, c, t)]);
+                acc += w * w;
+            }
+    }
+    const double a = d.A[iv];
+    const double w_fst = cd - sz * a - d.bf[iv];
+    const double w_end = cd + sz * a - d.be[iv];
+    const double nrm = sqrt(acc + w_end * w_end);
+    double lam = 0.5 * (1.0 + w_fst / nrm);          // 0/0 -> NaN when the pre-image is 0, as in the reference (:1018)
+    if (lam == lam) lam = fmin(fmax(lam, 0.0), 1.0);  // np.clip keeps NaN; fmin/fmax would drop it
+    d.zf[iv] = (lam >= 1.0) ? w_fst : lam * nrm;
+    d.ze[iv] = lam * w_end;
+    if (ONLY_MULTIPLIER) {
+        d.lamc[iv] = lam;
+        return;
+    }
+    for (int j = j0; j < j1; ++j) {
+        const int fk = d.cidx[j];
+        const int f = fk / 3;
+        const double D = d.c_D[j];
+        const double lt = lam / D;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double w = D * (sB * d.B[idxF(d, f, c, t + s)] - d.bm[idxM(d, fk, s, c, t)]);
+                d.zm[idxM(d, fk, s, c, t)] = lt * w;
+            }
+    }
+}
+
+template <bool ONLY_MULTIPLIER>
 __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, double cd, int n_soc, int IC) {
     // Workgroups [n_soc, gridDim.x): the modes -> time transform of phi (independent of the projection, same launch)
     if ((int)blockIdx.x >= n_soc) {
@@ -42,50 +87,10 @@ __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, doub
     const int tile = xcd_tile(blockIdx.x % G8, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
     const int v0 = tile * d.VT;
-    const double sB = sz * INV_SQRT3;
     for (int e = (blockIdx.x / G8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
         const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
         if (v >= d.V || t >= d.T) continue;
-        const int iv = idxV(d, v, t);
-        const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
-        double acc = 0.0;
-        for (int j = j0; j < j1; ++j) {
-            const int fk = d.cidx[j];
-            const int f = fk / 3;
-            const double D = d.c_D[j];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double w = D * (sB * d.B[idxF(d, f, c, t + s)] - d.bm[idxM(d, fk, s, c, t)]);
-                    acc += w * w;
-                }
-        }
-        const double a = d.A[iv];
-        const double w_fst = cd - sz * a - d.bf[iv];
-        const double w_end = cd + sz * a - d.be[iv];
-        const double nrm = sqrt(acc + w_end * w_end);
-        double lam = 0.5 * (1.0 + w_fst / nrm);          // 0/0 -> NaN when the pre-image is 0, as in the reference (:1018)
-        if (lam == lam) lam = fmin(fmax(lam, 0.0), 1.0);  // np.clip keeps NaN; fmin/fmax would drop it
-        d.zf[iv] = (lam >= 1.0) ? w_fst : lam * nrm;
-        d.ze[iv] = lam * w_end;
-        if (ONLY_MULTIPLIER) {
-            d.lamc[iv] = lam;
-            continue;
-        }
-        for (int j = j0; j < j1; ++j) {
-            const int fk = d.cidx[j];
-            const int f = fk / 3;
-            const double D = d.c_D[j];
-            const double lt = lam / D;
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double w = D * (sB * d.B[idxF(d, f, c, t + s)] - d.bm[idxM(d, fk, s, c, t)]);
-                    d.zm[idxM(d, fk, s, c, t)] = lt * w;
-                }
-        }
+        soc_element<ONLY_MULTIPLIER>(d, v, t, sz, cd);
     }
 }
 
@@ -155,7 +160,16 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps) {
 // to memory, the solver's input  bhat[v][a] = sum_t Q[t][a] b[v][t]  is written instead.
 // 1024 threads: one right-hand-side value (a corner walk) per thread.
 constexpr int RHS_NB = 1024;
-__global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double eps, double *__restrict__ bhat, int IC) {
+// Workgroups [n_rhs, gridDim.x): the cone projection of a tile (it reads nothing this kernel or the solve writes
+// and is as latency-bound as the corner walks here: one launch instead of two).
+__global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double eps, double *__restrict__ bhat, int IC, int n_rhs, double sz, double cd) {
+    if ((int)blockIdx.x >= n_rhs) {
+        const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
+        if (st >= d.n_vtiles) return;
+        const int e = threadIdx.x, v = st * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (v < d.V && t < d.T) soc_element<true>(d, v, t, sz, cd);
+        return;
+    }
     extern __shared__ double tm_lds[];
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
     double *Qs = tm_lds;                 // [IC][TP]
@@ -183,14 +197,14 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, doub
     modes_from_tile_mfma<RHS_NB / 64>(d, d.Qpad, xs_m, v0, bhat);
 }
 
-int launch_rhs(Ctx *c) {
+int launch_rhs(Ctx *c, bool with_soc) {
     const int g = xcd_grid(c->d.n_vtiles);
     if (rhs_writes_modes(c) && time_modes_mfma_ok(c->d))
         hipLaunchKernelGGL(k_rhs_modes_mfma, dim3((c->d.V + TM_ROWS - 1) / TM_ROWS), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
                            c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0);
     else if (rhs_writes_modes(c))
-        hipLaunchKernelGGL(k_rhs_modes, dim3(g), dim3(RHS_NB), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps,
-                           c->d.cg_p0, time_modes_chunk(c->d));
+        hipLaunchKernelGGL(k_rhs_modes, dim3(with_soc ? 2 * g : g), dim3(RHS_NB), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
+                           c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d);
     else
         hipLaunchKernelGGL(k_rhs, dim3(g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps);
     DOTS_HIP(hipGetLastError());
