@@ -242,7 +242,7 @@ inline bool rhs_writes_modes(const Ctx *c) {
 
 inline bool soc_takes_inverse(const Ctx *c) { return rhs_writes_modes(c) && !time_modes_mfma_ok(c->d); }
 // ... or the projection itself rides in the right-hand-side launch (enqueue-only iterations; TILE_ELEMS threads per tile)
-inline bool rhs_takes_soc(const Ctx *c) { return c->soc_with_rhs && rhs_writes_modes(c) && !time_modes_mfma_ok(c->d); }
+inline bool rhs_takes_soc(const Ctx *c) { return c->soc_with_rhs && rhs_writes_modes(c); }
 
 int64_t array_count_host(const Dev &d, int array_id);    // elements in the reference layout
 int64_t array_count_device(const Dev &d, int array_id);  // elements in the device layout

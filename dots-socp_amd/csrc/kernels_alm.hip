@@ -185,7 +185,14 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double ep
 }
 
 // T + 1 >= 64: 32 vertices per workgroup, the transform on the matrix cores.
-__global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, double eps, double *__restrict__ bhat) {
+__global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, double eps, double *__restrict__ bhat, int n_rhs, double sz, double cd) {
+    if ((int)blockIdx.x >= n_rhs) {      // riders: the cone projection of a tile, as in k_rhs_modes
+        const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
+        if (st >= d.n_vtiles) return;
+        const int e = threadIdx.x, v = st * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (v < d.V && t < d.T) soc_element<true>(d, v, t, sz, cd);
+        return;
+    }
     extern __shared__ double xs_m[];                    // [TM_ROWS][TP + 1]
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
     const int v0 = blockIdx.x * TM_ROWS;
@@ -199,9 +206,11 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, doub
 
 int launch_rhs(Ctx *c, bool with_soc) {
     const int g = xcd_grid(c->d.n_vtiles);
-    if (rhs_writes_modes(c) && time_modes_mfma_ok(c->d))
-        hipLaunchKernelGGL(k_rhs_modes_mfma, dim3((c->d.V + TM_ROWS - 1) / TM_ROWS), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
-                           c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0);
+    if (rhs_writes_modes(c) && time_modes_mfma_ok(c->d)) {
+        const int n_rhs = (c->d.V + TM_ROWS - 1) / TM_ROWS;
+        hipLaunchKernelGGL(k_rhs_modes_mfma, dim3(n_rhs + (with_soc ? g : 0)), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
+                           c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, c->prm.scale_z, c->prm.const_d);
+    }
     else if (rhs_writes_modes(c))
         hipLaunchKernelGGL(k_rhs_modes, dim3(with_soc ? 2 * g : g), dim3(RHS_NB), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
                            c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d);
