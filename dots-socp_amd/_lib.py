@@ -27,7 +27,8 @@ EXPORTS = [
     "dots_sync", "dots_upload", "dots_download", "dots_array_count", "dots_step", "dots_run_phase", "dots_kkt",
     "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
-    "dots_step_begin", "dots_step_end", "dots_shard_elems", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_stream_wait",
+    "dots_step_begin", "dots_step_end", "dots_shard_elems", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
+    "dots_symbolic_build", "dots_symbolic_front_rows", "dots_symbolic_copy", "dots_symbolic_free",
 ]
 
 
@@ -156,11 +157,25 @@ def load():
     lib.dots_front_pitch.argtypes = [vp]
     lib.dots_step_flags.argtypes = [vp, C.c_uint32]
     lib.dots_stream_wait.argtypes = [vp, vp, C.c_int]
+    i64p = C.POINTER(C.c_int64)
+    lib.dots_tree_build.argtypes = [C.c_int32, _i32p, _i32p, _f64p, C.c_int32, C.POINTER(vp)]
+    lib.dots_tree_nodes.argtypes = [vp]
+    lib.dots_tree_nodes.restype = C.c_int64
+    lib.dots_tree_copy.argtypes = [vp, i64p, i64p, _i32p, _i32p, _i32p]
+    lib.dots_tree_free.argtypes = [vp]
+    lib.dots_tree_free.restype = None
+    lib.dots_symbolic_build.argtypes = [C.c_int32, _i32p, _i32p, C.c_int64, i64p, i64p, _i32p, C.POINTER(vp)]
+    lib.dots_symbolic_front_rows.argtypes = [vp]
+    lib.dots_symbolic_front_rows.restype = C.c_int64
+    lib.dots_symbolic_copy.argtypes = [vp, _i32p, _i32p, _i32p, _i32p]
+    lib.dots_symbolic_free.argtypes = [vp]
+    lib.dots_symbolic_free.restype = None
     lib.dots_device_bytes.argtypes = [vp]
     lib.dots_device_bytes.restype = C.c_int64
     for n in EXPORTS:
         f = getattr(lib, n)
-        if n not in ("dots_last_error", "dots_array_count", "dots_device_bytes", "dots_shard_elems"):
+        if n not in ("dots_last_error", "dots_array_count", "dots_device_bytes", "dots_shard_elems", "dots_tree_nodes", "dots_tree_free",
+                     "dots_symbolic_front_rows", "dots_symbolic_free"):
             f.restype = C.c_int
     if lib.dots_abi_version() != ABI_VERSION:
         raise HipLibraryError("libdotsocp_hip.so ABI version mismatch; rebuild it")

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libdotsocp_hip.so")
-SOURCES = ["dots_api.hip", "kernels_alm.hip", "kernels_cg.hip", "kernels_mg.hip", "kernels_front.hip", "kernels_factor.hip", "kernels_kkt.hip"]
+SOURCES = ["dots_api.hip", "kernels_alm.hip", "kernels_cg.hip", "kernels_mg.hip", "kernels_front.hip", "kernels_factor.hip", "dissect.hip", "kernels_kkt.hip"]
 HEADERS = [os.path.join(CSRC, "dots_dev.h"), os.path.join(PKG_DIR, "..", "include", "dots_socp_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]

@@ -58,10 +58,13 @@ def _neighbour_ranges(indptr, rows):
     return pos, local
 
 
-def nested_dissection(indptr, indices, coords, leaf=16) -> Dissection:
-    """Geometric nested dissection: a subset is cut at the median of its principal axis, the separator is
+def nested_dissection(indptr, indices, coords, leaf=16, native=True) -> Dissection:
+    """Geometric nested dissection (``native``: the C++ implementation in libdotsocp_hip.so, csrc/dissect.hip --
+    host code, ~10x faster; ``native=False``: this module's numpy recursion, the reference for the tests): a subset is cut at the median of its principal axis, the separator is
     the smaller of the two one-sided vertex boundaries of the cut (so it is a separator of the GRAPH
     whatever the embedding looks like); subsets of at most `leaf` vertices become dense leaves."""
+    if native:
+        return _nested_dissection_native(indptr, indices, coords, leaf)
     indptr = np.asarray(indptr, dtype=np.int64)
     indices = np.asarray(indices, dtype=np.int64)
     coords = np.asarray(coords, dtype=np.float64)
@@ -130,6 +133,62 @@ def nested_dissection(indptr, indices, coords, leaf=16) -> Dissection:
     order = np.concatenate(seps)
     assert order.size == V and np.array_equal(np.sort(order), np.arange(V))
     return Dissection(order=order, sep_ptr=sep_ptr, child=child, parent=parent, height=height)
+
+
+def _ptr(a, ctype):
+    import ctypes as C
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _nested_dissection_native(indptr, indices, coords, leaf):
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    ip = np.ascontiguousarray(indptr, dtype=np.int32)
+    ix = np.ascontiguousarray(indices, dtype=np.int32)
+    xyz = np.ascontiguousarray(coords, dtype=np.float64)
+    V = ip.size - 1
+    h = C.c_void_p()
+    _lib.check(lib.dots_tree_build(V, _ptr(ip, C.c_int32), _ptr(ix, C.c_int32), _ptr(xyz, C.c_double), int(leaf), C.byref(h)), "dots_tree_build")
+    try:
+        n = int(lib.dots_tree_nodes(h))
+        order, sep_ptr = np.empty(V, dtype=np.int64), np.empty(n + 1, dtype=np.int64)
+        child, parent, height = np.empty((n, 2), dtype=np.int32), np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        _lib.check(lib.dots_tree_copy(h, _ptr(order, C.c_int64), _ptr(sep_ptr, C.c_int64), _ptr(child, C.c_int32), _ptr(parent, C.c_int32),
+                                      _ptr(height, C.c_int32)), "dots_tree_copy")
+    finally:
+        lib.dots_tree_free(h)
+    return Dissection(order=order, sep_ptr=sep_ptr, child=child, parent=parent, height=height)
+
+
+def symbolic_native(diss: Dissection, indptr, indices):
+    """(node_b, front_idx, pull0, pull1) of the tree on the graph, from csrc/dissect.hip (same result as
+    ``symbolic`` + the front / pull loops of ``factorize``)."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    ip = np.ascontiguousarray(indptr, dtype=np.int32)
+    ix = np.ascontiguousarray(indices, dtype=np.int32)
+    order = np.ascontiguousarray(diss.order, dtype=np.int64)
+    sep_ptr = np.ascontiguousarray(diss.sep_ptr, dtype=np.int64)
+    child = np.ascontiguousarray(diss.child, dtype=np.int32)
+    n = diss.n_nodes
+    h = C.c_void_p()
+    _lib.check(lib.dots_symbolic_build(ip.size - 1, _ptr(ip, C.c_int32), _ptr(ix, C.c_int32), n, _ptr(order, C.c_int64), _ptr(sep_ptr, C.c_int64),
+                                       _ptr(child, C.c_int32), C.byref(h)), "dots_symbolic_build")
+    try:
+        rows = int(lib.dots_symbolic_front_rows(h))
+        node_b = np.empty(n, dtype=np.int32)
+        front_idx, pull0, pull1 = (np.empty(rows, dtype=np.int32) for _ in range(3))
+        _lib.check(lib.dots_symbolic_copy(h, _ptr(node_b, C.c_int32), _ptr(front_idx, C.c_int32), _ptr(pull0, C.c_int32), _ptr(pull1, C.c_int32)),
+                   "dots_symbolic_copy")
+    finally:
+        lib.dots_symbolic_free(h)
+    return node_b, front_idx, pull0, pull1
 
 
 # ------------------------------------------------------------------------------------------------
@@ -257,10 +316,14 @@ def factorize(K: sp.csr_matrix, mass, shifts, diss: Dissection, pitch=None, work
     A = shifts.size
     P = int(pitch) if pitch is not None else A
     V = K.shape[0]
-    bds, pos = symbolic(diss, indptr, indices)
     nn = diss.n_nodes
     node_n = np.diff(diss.sep_ptr).astype(np.int32)
-    node_b = np.asarray([b.size for b in bds], dtype=np.int32)
+    if numeric:
+        bds, pos = symbolic(diss, indptr, indices)
+        node_b = np.asarray([b.size for b in bds], dtype=np.int32)
+    else:       # structure only: the C++ symbolic phase
+        bds = None
+        node_b, front_idx, pull0n, pull1n = symbolic_native(diss, K.indptr, K.indices)
     m = node_n.astype(np.int64) + node_b
     node_foff = np.zeros(nn, dtype=np.int64)
     node_foff[1:] = np.cumsum(m * node_n)[:-1]
@@ -269,19 +332,22 @@ def factorize(K: sp.csr_matrix, mass, shifts, diss: Dissection, pitch=None, work
     node_uoff = np.zeros(nn, dtype=np.int64)
     node_uoff[1:] = np.cumsum(node_b.astype(np.int64))[:-1]
     total_f = int((m * node_n).sum())
-    front_idx = np.empty(int(m.sum()), dtype=np.int32)
-    pull = [np.full(front_idx.size, -1, dtype=np.int32), np.full(front_idx.size, -1, dtype=np.int32)]
-    frontpos = np.full(V, -1, dtype=np.int64)
-    for p in range(nn):
-        front = np.concatenate([diss.order[diss.sep_ptr[p]:diss.sep_ptr[p + 1]], bds[p]])
-        io = node_ioff[p]
-        front_idx[io:io + front.size] = front
-        frontpos[front] = np.arange(front.size)
-        for k, c in enumerate(diss.child[p]):
-            if c >= 0:
-                cm = frontpos[bds[c]]
-                pull[k][io + cm] = np.arange(cm.size, dtype=np.int32)
-        frontpos[front] = -1
+    if numeric:
+        front_idx = np.empty(int(m.sum()), dtype=np.int32)
+        pull = [np.full(front_idx.size, -1, dtype=np.int32), np.full(front_idx.size, -1, dtype=np.int32)]
+        frontpos = np.full(V, -1, dtype=np.int64)
+        for p in range(nn):
+            front = np.concatenate([diss.order[diss.sep_ptr[p]:diss.sep_ptr[p + 1]], bds[p]])
+            io = node_ioff[p]
+            front_idx[io:io + front.size] = front
+            frontpos[front] = np.arange(front.size)
+            for k, c in enumerate(diss.child[p]):
+                if c >= 0:
+                    cm = frontpos[bds[c]]
+                    pull[k][io + cm] = np.arange(cm.size, dtype=np.int32)
+            frontpos[front] = -1
+    else:
+        pull = [pull0n, pull1n]
 
     scale = float(np.abs(K.diagonal()).max())
     singular = np.abs(shifts) * float(mass.max()) <= 1e-13 * scale

@@ -305,6 +305,27 @@ typedef struct dots_front_desc {
 } dots_front_desc;
 
 int dots_front_setup(dots_ctx *ctx, const dots_front_desc *desc);
+
+/* Host-side helpers for dots_front_desc (no device work; the Python reference implementations are in
+ * dots-socp_amd/frontal.py).
+ * dots_tree_build: geometric nested dissection of the graph (CSR pattern of K, 0-based) of `n_vertices` points
+ * `xyz` [V][3]: subsets are cut at the median of their longest bounding-box side (principal axis above 512
+ * vertices), the separator is the smaller one-sided vertex boundary of the cut, subsets of <= `leaf` vertices
+ * become leaves.  Nodes are numbered children first; copy out with dots_tree_copy: order [V] (vertex eliminated
+ * at position k), sep_ptr [n+1], child [n][2], parent [n], height [n].
+ * dots_symbolic_build: boundary sets of the tree on the graph given in the numbering `order` refers to:
+ * node_b [n], and per front row (separator rows first; dots_symbolic_front_rows of them) front_idx, pull0, pull1. */
+typedef struct dots_tree dots_tree;
+typedef struct dots_symbolic dots_symbolic;
+int dots_tree_build(int32_t n_vertices, const int32_t *indptr, const int32_t *indices, const double *xyz, int32_t leaf, dots_tree **out);
+int64_t dots_tree_nodes(const dots_tree *tree);
+int dots_tree_copy(const dots_tree *tree, int64_t *order, int64_t *sep_ptr, int32_t *child, int32_t *parent, int32_t *height);
+void dots_tree_free(dots_tree *tree);
+int dots_symbolic_build(int32_t n_vertices, const int32_t *indptr, const int32_t *indices, int64_t n_nodes, const int64_t *order,
+                        const int64_t *sep_ptr, const int32_t *child, dots_symbolic **out);
+int64_t dots_symbolic_front_rows(const dots_symbolic *sym);
+int dots_symbolic_copy(const dots_symbolic *sym, int32_t *node_b, int32_t *front_idx, int32_t *pull0, int32_t *pull1);
+void dots_symbolic_free(dots_symbolic *sym);
 int dots_front_enable(dots_ctx *ctx, int on);
 /* the mode pitch `values` must be laid out with (power of two >= the context's mode count, >= 8) */
 int dots_front_pitch(dots_ctx *ctx);

@@ -25,11 +25,13 @@ CASES = [("sphere", dict(level=3)), ("refplane", dict(n=12)), ("torus", dict(nu=
 
 
 @pytest.mark.parametrize("name,kw", CASES)
-@pytest.mark.parametrize("reorder", [True, "nd"])
+@pytest.mark.parametrize("reorder", [True, "nd", "python"])
 def test_tree_and_structure(name, kw, reorder):
-    plan, K = problem(name, reorder, **kw)
+    """The C++ dissection (csrc/dissect.hip: the default, also behind reorder="nd") and the numpy reference."""
+    plan, K = problem(name, reorder == "nd" and "nd" or True, **kw)
     V = plan.n_vertices
-    diss = plan.dissection if reorder == "nd" else frontal.nested_dissection(K.indptr, K.indices, plan.vertices, leaf=8)
+    diss = plan.dissection if reorder == "nd" else frontal.nested_dissection(K.indptr, K.indices, plan.vertices, leaf=8,
+                                                                             native=reorder != "python")
     if reorder == "nd":
         assert np.array_equal(diss.order, np.arange(V))      # the device numbering IS the elimination order
     assert np.array_equal(np.sort(diss.order), np.arange(V))
@@ -76,3 +78,25 @@ def test_factor_solves_every_mode(name, kw, reorder):
     assert ff2.grounded.size == 0
     x2 = frontal_cpu.solve(ff2, b[:, :2])
     assert np.max(np.abs((K + 0.5 * M) @ x2[:, 0] - b[:, 0])) < 1e-10 * np.max(np.abs(b[:, 0]))
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+def test_native_symbolic_equals_python_symbolic(name, kw):
+    plan, K = problem(name, "nd", **kw)
+    shifts = plan.time_eigs[:2] + 0.3
+    a = frontal.factorize(K, plan.mass_vert, shifts, plan.dissection, numeric=False)     # C++ symbolic phase
+    b = frontal.factorize(K, plan.mass_vert, shifts, plan.dissection, numeric=True)      # numpy
+    for key in ("node_n", "node_b", "node_foff", "node_ioff", "node_uoff", "node_child", "front_idx", "pull0", "pull1", "level_ptr", "level_nodes"):
+        assert np.array_equal(getattr(a, key), getattr(b, key)), key
+    assert a.values is None and b.values is not None and a.update_rows == b.update_rows
+
+
+def test_native_dissection_is_at_least_as_good_as_the_reference_one():
+    g, _ = meshes.example("sphere", level=4)
+    plan = geometry.build_plan(7, g, reorder=False)
+    K = sp.csr_matrix((plan.lap_val, plan.lap_col, plan.lap_rowptr), shape=(plan.n_vertices,) * 2)
+    size = {}
+    for native in (True, False):
+        d = frontal.nested_dissection(K.indptr, K.indices, plan.vertices, leaf=16, native=native)
+        size[native] = frontal.factorize(K, plan.mass_vert, plan.time_eigs[:1] + 1.0, d, numeric=False).stats["factor_entries_per_mode"]
+    assert size[True] <= 1.05 * size[False]
