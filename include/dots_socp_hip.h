@@ -58,7 +58,9 @@ enum dots_kkt_id {
 /* which Laplacian solver runs in step 1 (replaces laplacian_inverse_socp.py:11-61) */
 enum dots_lap_solver {
     DOTS_LAP_SPACETIME_PCG = 0, /* Jacobi-PCG on the assembled space-time operator            */
-    DOTS_LAP_MODAL_PCG = 1      /* time eigen-modes decoupled (DCT), batched shifted-surface PCG */
+    DOTS_LAP_MODAL_PCG = 1      /* time eigen-modes decoupled (DCT): batched shifted-surface PCG, or -- once a factor is
+                                   installed with dots_front_setup -- the direct multifrontal sweeps (the default of
+                                   the Python driver: lap_solver="modal_direct")                  */
 };
 
 /*
@@ -165,7 +167,7 @@ int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
 int dots_step_flags(dots_ctx *ctx, uint32_t flags);
 
 /* One ALM iteration split around the only exchange of the multi-GPU path (mode-sharded solve):
- *   dots_step_begin  right-hand side + PCG for this context's time modes; the mode-space solution
+ *   dots_step_begin  right-hand side + solve (direct sweeps or PCG) for this context's time modes; the mode-space solution
  *                    [V][pitch] (dots_shard_elems doubles) is copied to the DEVICE buffer `send`
  *   (caller)         all-gather of `send` over the ranks into `recv` = [n_ranks][V][pitch]  (RCCL)
  *   dots_step_end    inverse time transform from `recv`, then the cone projection and the
