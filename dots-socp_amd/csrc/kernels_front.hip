@@ -33,55 +33,90 @@ struct FrontArgs {
 
 __device__ __forceinline__ int64_t front_row(const FrontDev &f, int k) { return f.vmap ? f.vmap[k] : k; }
 
-// Sum `acc` over the threads of the workgroup that share a mode (the parts q of the dot products): lanes of a
-// wavefront first (xor-shuffles), then one LDS slot per (row, wavefront, mode).  Returns nothing; the caller reads
-// red[(r * NW + w) * TP + a] for w < NW after the barrier.  TP <= 64: a wavefront holds 64 / TP parts.
-template <int NB, int RB>
-__device__ __forceinline__ void front_fold(double (&acc)[RB], double *red, int TP, int a, int tid) {
+// VEC consecutive modes per lane (VEC = 2: 16-byte loads, twice as many parts q of a dot product per workgroup).
+template <int VEC> struct Vd { double v[VEC]; };
+template <int VEC> __device__ __forceinline__ Vd<VEC> vload(const double *p) {
+    Vd<VEC> o;
+    if (VEC == 2) {
+        const double2 t = *reinterpret_cast<const double2 *>(p);
+        o.v[0] = t.x;
+        o.v[VEC - 1] = t.y;
+    } else {
+        o.v[0] = *p;
+    }
+    return o;
+}
+template <int VEC> __device__ __forceinline__ void vstore(double *p, const Vd<VEC> &x) {
+    if (VEC == 2) *reinterpret_cast<double2 *>(p) = make_double2(x.v[0], x.v[VEC - 1]);
+    else *p = x.v[0];
+}
+
+// Sum `acc` over the threads of the workgroup that share their modes (the parts q of the dot products): lanes of a
+// wavefront first (xor-shuffles), then one LDS slot per (row, wavefront, mode); the caller reads them back with
+// front_folded after the barrier inside.  TPv = TP / VEC lanes hold one row part; TPv <= 64.
+template <int NB, int RB, int VEC>
+__device__ __forceinline__ void front_fold(Vd<VEC> (&acc)[RB], double *red, int TP, int a, int tid) {
     constexpr int NW = NB / 64;
-    if (TP <= 64) {
+    const int TPv = TP / VEC;
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            double s = acc[r];
-            for (int o = 32; o >= TP; o >>= 1) s += __shfl_xor(s, o, 64);
-            acc[r] = s;
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            double s = acc[r].v[c];
+            for (int o = 32; o >= TPv; o >>= 1) s += __shfl_xor(s, o, 64);
+            acc[r].v[c] = s;
         }
-        if ((tid & 63) < TP) {
+    if ((tid & 63) < TPv) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) red[(r * NW + (tid >> 6)) * TP + a] = acc[r];
-        }
-    } else {      // TP = 128 / 256: a wavefront covers part of one row of modes; one slot per thread
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
-        for (int r = 0; r < RB; ++r) red[r * NB + tid] = acc[r];
+            for (int c = 0; c < VEC; ++c) red[(r * NW + (tid >> 6)) * TP + a + c] = acc[r].v[c];
     }
     __syncthreads();
 }
-template <int NB>
-__device__ __forceinline__ double front_folded(const double *red, int r, int TP, int sh, int a) {
+template <int NB, int VEC>
+__device__ __forceinline__ Vd<VEC> front_folded(const double *red, int r, int TP, int a) {
     constexpr int NW = NB / 64;
-    double s = 0.0;
-    if (TP <= 64) {
-        for (int w = 0; w < NW; ++w) s += red[(r * NW + w) * TP + a];
-    } else {
-        for (int k = 0; k < (NB >> sh); ++k) s += red[r * NB + (k << sh) + a];
+    Vd<VEC> s;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        double t = 0.0;
+        for (int w = 0; w < NW; ++w) t += red[(r * NW + w) * TP + a + c];
+        s.v[c] = t;
     }
     return s;
 }
+// one thread per mode and row part when a row of modes is wider than a wavefront (TP / VEC > 64)
+template <int NB, int RB>
+__device__ __forceinline__ void front_fold_wide(Vd<1> (&acc)[RB], double *red, int tid) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) red[r * NB + tid] = acc[r].v[0];
+    __syncthreads();
+}
+template <int NB>
+__device__ __forceinline__ Vd<1> front_folded_wide(const double *red, int r, int sh, int a) {
+    Vd<1> s;
+    s.v[0] = 0.0;
+    for (int k = 0; k < (NB >> sh); ++k) s.v[0] += red[r * NB + (k << sh) + a];
+    return s;
+}
 
-// forward sweep of one tree height.  Workgroup = (node, rb <= RB rows); thread = (mode a, part q of the dot product).
-// Every load of the loop body is unconditional (rows past the block are clamped to its first row and their sums
-// dropped; leaves read their "children's" planes from the zero pad at the start of W; the upper triangle of L^-1
-// is stored as zeros), so that the compiler issues the RB + 3 loads of a step back to back and waits once.
+// forward sweep of one tree height.  Workgroup = (node, rb <= RB rows); thread = (VEC modes from a, part q of the dot
+// product).  Every load of the loop body is unconditional (rows past the block are clamped to its first row and
+// their sums dropped; leaves read their "children's" planes from the zero pad at the start of W; the upper triangle
+// of L^-1 is stored as zeros), so that the compiler issues the RB + 3 loads of a step back to back and waits once.
 // RB is the level's exact block size (1, 2 or 4: no duplicate loads); LEAF (tree height 0): no update planes to read.
-template <int NB, int RB, bool VMAP, bool LEAF>
+template <int NB, int RB, bool VMAP, bool LEAF, int VEC>
 __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const FrontWork *__restrict__ desc, int rb, const double *__restrict__ bhat,
                                                   double *__restrict__ Y) {
-    __shared__ double red[RB * (NB / 64) * 64];
+    __shared__ double red[RB * (NB / 64) * 64 * VEC];
     const FrontWork wk = desc[blockIdx.x];
     const FrontNode &nd = wk.nd;
     const int row0 = wk.first;
     const int sh = g.sh, tid = threadIdx.x;
-    const int a = tid & (g.TP - 1), q = tid >> sh, Q = NB >> sh;
+    const int shv = VEC == 2 ? sh - 1 : sh;                      // log2 of the lanes per row part
+    const int a = (tid & ((g.TP / VEC) - 1)) * VEC, q = tid >> shv, Q = NB >> shv;
+    const bool wide = (g.TP / VEC) > 64;                         // only with VEC == 1
     const int n = nd.n, m = n + nd.b;
     const double *__restrict__ Fp = f.F + (nd.foff << sh) + a;
     const double *__restrict__ W0 = f.W + (nd.woff << sh) + a;         // child 0's plane; child 1's is m rows further
@@ -89,11 +124,12 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
     const bool live = a < g.ncol;
     const int nr = min(rb, m - row0);
 
-    double acc[RB];
+    Vd<VEC> acc[RB];
     const double *rowp[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-        acc[r] = 0.0;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[r].v[c] = 0.0;
         rowp[r] = Fp + (((int64_t)(r < nr ? row0 + r : row0) * n) << sh);
     }
     // where this thread's (first) update row goes in the parent's plane: loaded now, needed after the fold
@@ -105,79 +141,104 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
         for (int j = q; j < jmax; j += Q) {
             const int64_t jo = (int64_t)j << sh;
             const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
-            const double wb = bhat[(row << sh) + a];
-            const double w0 = LEAF ? 0.0 : W0[jo], w1 = LEAF ? 0.0 : W0[plane + jo];
-            double fv[RB];
+            const Vd<VEC> wb = vload<VEC>(bhat + (row << sh) + a);
+            Vd<VEC> w0, w1, fv[RB];
+            if (!LEAF) {
+                w0 = vload<VEC>(W0 + jo);
+                w1 = vload<VEC>(W0 + plane + jo);
+            }
 #pragma unroll
-            for (int r = 0; r < RB; ++r) fv[r] = rowp[r][jo];
-            const double w = LEAF ? wb : wb - (w0 + w1);
+            for (int r = 0; r < RB; ++r) fv[r] = vload<VEC>(rowp[r] + jo);
 #pragma unroll
-            for (int r = 0; r < RB; ++r) acc[r] += fv[r] * w;
+            for (int c = 0; c < VEC; ++c) {
+                const double w = LEAF ? wb.v[c] : wb.v[c] - (w0.v[c] + w1.v[c]);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r].v[c] += fv[r].v[c] * w;
+            }
         }
     }
-    front_fold<NB, RB>(acc, red, g.TP, a, tid);
+    if (VEC == 1 && wide) front_fold_wide<NB, RB>(reinterpret_cast<Vd<1>(&)[RB]>(acc), red, tid);
+    else front_fold<NB, RB, VEC>(acc, red, g.TP, a, tid);
     for (int r = q; r < nr && live; r += Q) {
-        double s = front_folded<NB>(red, r, g.TP, sh, a);
+        Vd<VEC> s;
+        if (VEC == 1 && wide) s.v[0] = front_folded_wide<NB>(red, r, sh, a).v[0];
+        else s = front_folded<NB, VEC>(red, r, g.TP, a);
         const int i = row0 + r;
         if (i < n) {
-            Y[(front_row(f, nd.k0 + i) << sh) + a] = s;
+            vstore<VEC>(Y + (front_row(f, nd.k0 + i) << sh) + a, s);
         } else {   // update row: carry the children's contributions on, hand the sum to the parent's plane
-            if (!LEAF) s += W0[(int64_t)i << sh] + W0[plane + ((int64_t)i << sh)];
+            if (!LEAF) {
+                const Vd<VEC> c0 = vload<VEC>(W0 + ((int64_t)i << sh)), c1 = vload<VEC>(W0 + plane + ((int64_t)i << sh));
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) s.v[c] += c0.v[c] + c1.v[c];
+            }
             const int cm = r == q ? cm0 : f.cmap[nd.bdoff + (i - n)];
-            f.W[((nd.parent_w + cm) << sh) + a] = s;
+            vstore<VEC>(f.W + ((nd.parent_w + cm) << sh) + a, s);
         }
     }
 }
 
 // backward sweep of one tree height.  Workgroup = (node, cb <= RB columns).  Same load discipline.
-template <int NB, int RB, bool VMAP>
+template <int NB, int RB, bool VMAP, int VEC>
 __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const FrontWork *__restrict__ desc, int cb, const double *__restrict__ Y,
                                                   double *X) {
-    __shared__ double red[RB * (NB / 64) * 64];
+    __shared__ double red[RB * (NB / 64) * 64 * VEC];
     const FrontWork wk = desc[blockIdx.x];
     const FrontNode &nd = wk.nd;
     const int col0 = wk.first;
     const int sh = g.sh, tid = threadIdx.x;
-    const int a = tid & (g.TP - 1), q = tid >> sh, Q = NB >> sh;
+    const int shv = VEC == 2 ? sh - 1 : sh;
+    const int a = (tid & ((g.TP / VEC) - 1)) * VEC, q = tid >> shv, Q = NB >> shv;
+    const bool wide = (g.TP / VEC) > 64;
     const int n = nd.n, m = n + nd.b;
     const double *__restrict__ Fp = f.F + (nd.foff << sh) + a;
     const int *__restrict__ bdv = f.bd_vertex + nd.bdoff;
     const bool live = a < g.ncol;
     const int nc = min(cb, n - col0);
 
-    double acc[RB];
+    Vd<VEC> acc[RB];
     int64_t co[RB];      // column offsets (columns past the block: its first column, sums dropped)
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-        acc[r] = 0.0;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[r].v[c] = 0.0;
         co[r] = (int64_t)(r < nc ? col0 + r : col0) << sh;
     }
     if (live) {
         // rows of the separator: y_p.  Column i of L^-1 is zero above the diagonal: start at the block's first column
         for (int j = col0 + q; j < n; j += Q) {
             const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
-            const double v = Y[(row << sh) + a];
+            const Vd<VEC> v = vload<VEC>(Y + (row << sh) + a);
             const double *__restrict__ Fj = Fp + (((int64_t)j * n) << sh);
-            double fv[RB];
+            Vd<VEC> fv[RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) fv[r] = Fj[co[r]];
+            for (int r = 0; r < RB; ++r) fv[r] = vload<VEC>(Fj + co[r]);
 #pragma unroll
-            for (int r = 0; r < RB; ++r) acc[r] += fv[r] * v;
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc[r].v[c] += fv[r].v[c] * v.v[c];
         }
         // boundary rows: -x of the ancestors (written by the launches of greater heights)
         for (int j = n + q; j < m; j += Q) {
-            const double v = X[((int64_t)bdv[j - n] << sh) + a];
+            const Vd<VEC> v = vload<VEC>(X + ((int64_t)bdv[j - n] << sh) + a);
             const double *__restrict__ Fj = Fp + (((int64_t)j * n) << sh);
-            double fv[RB];
+            Vd<VEC> fv[RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) fv[r] = Fj[co[r]];
+            for (int r = 0; r < RB; ++r) fv[r] = vload<VEC>(Fj + co[r]);
 #pragma unroll
-            for (int r = 0; r < RB; ++r) acc[r] -= fv[r] * v;
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc[r].v[c] -= fv[r].v[c] * v.v[c];
         }
     }
-    front_fold<NB, RB>(acc, red, g.TP, a, tid);
-    for (int r = q; r < nc && live; r += Q)
-        X[(front_row(f, nd.k0 + col0 + r) << sh) + a] = front_folded<NB>(red, r, g.TP, sh, a);
+    if (VEC == 1 && wide) front_fold_wide<NB, RB>(reinterpret_cast<Vd<1>(&)[RB]>(acc), red, tid);
+    else front_fold<NB, RB, VEC>(acc, red, g.TP, a, tid);
+    for (int r = q; r < nc && live; r += Q) {
+        Vd<VEC> s;
+        if (VEC == 1 && wide) s.v[0] = front_folded_wide<NB>(red, r, sh, a).v[0];
+        else s = front_folded<NB, VEC>(red, r, g.TP, a);
+        vstore<VEC>(X + (front_row(f, nd.k0 + col0 + r) << sh) + a, s);
+    }
 }
 
 void front_release(Ctx *c) {
@@ -407,15 +468,28 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
     if (f.n_nodes == 0) { set_error("front_solve: no factor installed"); return DOTS_ERR_STATE; }
     const FrontArgs g{d.tp_shift, d.TP, d.cg_ncol};
     const bool vm = f.vmap != nullptr;
+    // two modes per lane (16-byte loads): pays where the sweeps are bandwidth-bound (measured: +6 % at torus100k, +13 % at
+    // T = 127; -2 % on the latency-bound sphere10k, where it is left off)
+    const bool v2 = c->front_vec2 && d.TP >= 4 && d.TP <= 128 && (d.TP >= 64 || c->front_bytes > 1.0e9);
 #define FRONT_FWD(NBV, RBV, LEAFV)                                                                                                 \
     do {                                                                                                                           \
-        if (vm) hipLaunchKernelGGL((k_front_fwd<NBV, RBV, true, LEAFV>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);  \
-        else hipLaunchKernelGGL((k_front_fwd<NBV, RBV, false, LEAFV>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);    \
+        if (v2) {                                                                                                                  \
+            if (vm) hipLaunchKernelGGL((k_front_fwd<NBV, RBV, true, LEAFV, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);  \
+            else hipLaunchKernelGGL((k_front_fwd<NBV, RBV, false, LEAFV, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);    \
+        } else {                                                                                                                   \
+            if (vm) hipLaunchKernelGGL((k_front_fwd<NBV, RBV, true, LEAFV, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);  \
+            else hipLaunchKernelGGL((k_front_fwd<NBV, RBV, false, LEAFV, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);    \
+        }                                                                                                                          \
     } while (0)
 #define FRONT_BWD(NBV, RBV)                                                                                                        \
     do {                                                                                                                           \
-        if (vm) hipLaunchKernelGGL((k_front_bwd<NBV, RBV, true>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);         \
-        else hipLaunchKernelGGL((k_front_bwd<NBV, RBV, false>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);           \
+        if (v2) {                                                                                                                  \
+            if (vm) hipLaunchKernelGGL((k_front_bwd<NBV, RBV, true, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);  \
+            else hipLaunchKernelGGL((k_front_bwd<NBV, RBV, false, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);    \
+        } else {                                                                                                                   \
+            if (vm) hipLaunchKernelGGL((k_front_bwd<NBV, RBV, true, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);  \
+            else hipLaunchKernelGGL((k_front_bwd<NBV, RBV, false, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);    \
+        }                                                                                                                          \
     } while (0)
     for (int l = 0; l < f.n_levels; ++l) {
         const int n = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
