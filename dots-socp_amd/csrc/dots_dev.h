@@ -205,7 +205,7 @@ struct Ctx {
     int front_fwd_ptr[66]{}, front_bwd_ptr[66]{};   // workgroup ranges of the tree levels in fwd_desc / bwd_desc
     int front_fwd_rb[65]{}, front_bwd_cb[65]{};     // rows / columns per workgroup on each level
     int front_fwd_nb[65]{}, front_bwd_nb[65]{};     // threads per workgroup on each level (256, or 1024 where a level has few rows)
-    int front_vec2 = 1;           // two modes per lane in the sweeps (DOTS_FRONT_VEC2=0: one, for A/B measurements)
+    int front_vec2 = 1;           // two modes per lane in the sweeps (DOTS_FRONT_VEC2: 0 never, 1 where bandwidth-bound, 2 always)
     int front_rb_max = 4;         // most rows (columns) of a node per workgroup (DOTS_FRONT_RB: 1, 2 or 4, for A/B measurements)
     double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps)
     void *front_allocs[24]{};

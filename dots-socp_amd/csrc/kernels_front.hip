@@ -470,7 +470,7 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
     const bool vm = f.vmap != nullptr;
     // two modes per lane (16-byte loads): pays where the sweeps are bandwidth-bound (measured: +6 % at torus100k, +13 % at
     // T = 127; -2 % on the latency-bound sphere10k, where it is left off)
-    const bool v2 = c->front_vec2 && d.TP >= 4 && d.TP <= 128 && (d.TP >= 64 || c->front_bytes > 1.0e9);
+    const bool v2 = c->front_vec2 && d.TP >= 4 && d.TP <= 128 && (c->front_vec2 > 1 || d.TP >= 64 || c->front_bytes > 1.0e9);
 #define FRONT_FWD(NBV, RBV, LEAFV)                                                                                                 \
     do {                                                                                                                           \
         if (v2) {                                                                                                                  \
