@@ -243,10 +243,12 @@ static int check(dots_ctx *ctx) {
 // first half of an iteration: right-hand side + solve (for this context's modes)
 static int run_iteration_begin(Ctx *c, dots_step_stats *st) {
     int rc;
-    if (!st) {   // enqueue only
-        if ((rc = launch_rhs(c))) return rc;
+    if (!st) {   // enqueue only; the cone projection rides in the right-hand-side launch (run_iteration_end then skips it)
+        c->soc_in_begin = c->soc_with_rhs;
+        if ((rc = launch_rhs(c, c->soc_in_begin != 0))) return rc;
         return cg_solve(c, nullptr);
     }
+    c->soc_in_begin = 0;
     DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
     if ((rc = launch_rhs(c))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
@@ -265,7 +267,8 @@ static int run_iteration_end(Ctx *c, const double *gathered, dots_step_stats *st
     int rc;
     if (!st) {   // enqueue only
         if ((rc = cg_finish_sharded(c, gathered))) return rc;
-        if ((rc = launch_soc_projection(c, 1))) return rc;
+        if (!c->soc_in_begin && (rc = launch_soc_projection(c, 1))) return rc;
+        c->soc_in_begin = 0;
         c->zmid_stale = c->step_skip_zmid;
         return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
     }

@@ -198,6 +198,7 @@ struct Ctx {
     int mg_tail_rows = 256;       // levels with at most this many rows run inside the single tail launch (DOTS_MG_TAIL_ROWS)
     int cg_graph_mg = -1;
     int soc_with_rhs = 1;         // DOTS_SOC_WITH_RHS=0: keep the projection after the solve (A/B measurements)
+    int soc_in_begin = 0;         // the projection of the current sharded iteration already ran in dots_step_begin
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
     int zmid_stale = 0;           // z_mid does not belong to the current iterate
     FrontDev front{};             // multifrontal factor (n_nodes == 0: none)
@@ -320,8 +321,11 @@ __device__ __forceinline__ void modes_from_tile_mfma(const Dev &d, const double 
 // y[v0 + vl][j] = sum_i Qeff[i][j] xs[vl][i] for the tile staged in xs ([VT][TP + 1], zero padded), with
 // Qeff[i][j] = Q[i][j] (FWD: time -> modes) or Q[j][i] (modes -> time), staged through Qs in chunks of IC rows.
 // A thread computes up to four outputs that share their Q column.  All threads of the workgroup must call it.
+// Only the outputs j in [j0, j0 + jn) are stored, at y[(v << out_shift) + (j - j0)]  (defaults: all of them, pitch TP).
 template <bool FWD, int NB = BLOCK>
-__device__ __forceinline__ void modes_from_tile(const Dev &d, const double *Q, const double *xs, double *Qs, int IC, int v0, double *__restrict__ y) {
+__device__ __forceinline__ void modes_from_tile(const Dev &d, const double *Q, const double *xs, double *Qs, int IC, int v0, double *__restrict__ y,
+                                                int out_shift = -1, int j0 = 0, int jn = 1 << 30) {
+    if (out_shift < 0) out_shift = d.tp_shift;
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1, tid = threadIdx.x;
     const int j = tid & (TP - 1), g = tid >> d.tp_shift, G = NB >> d.tp_shift;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -343,11 +347,11 @@ __device__ __forceinline__ void modes_from_tile(const Dev &d, const double *Q, c
             }
         }
     }
-    if (j < n) {
+    if (j < n && j >= j0 && j - j0 < jn) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int vl = g + r * G;
-            if (vl < d.VT && v0 + vl < d.V) y[idxV(d, v0 + vl, j)] = acc[r];
+            if (vl < d.VT && v0 + vl < d.V) y[((int64_t)(v0 + vl) << out_shift) + (j - j0)] = acc[r];
         }
     }
 }

@@ -138,8 +138,17 @@ __device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r
     return -rhs;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps) {
+// Workgroups [n_rhs, gridDim.x) (when there are any): the cone projection, a quarter tile each, as in k_rhs_modes.
+__global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps, int n_rhs, double sz, double cd) {
     __shared__ double lds[4];
+    if ((int)blockIdx.x >= n_rhs) {
+        const int G8 = (gridDim.x - n_rhs) / (TILE_ELEMS / BLOCK), b = blockIdx.x - n_rhs;
+        const int st = xcd_tile(b % G8, d.n_vtiles);
+        if (st >= d.n_vtiles) return;
+        const int e = (b / G8) * BLOCK + threadIdx.x, v = st * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (v < d.V && t < d.T) soc_element<true>(d, v, t, sz, cd);
+        return;
+    }
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
     double part[1] = {0.0};
     if (tile < d.n_vtiles) {
@@ -215,7 +224,8 @@ int launch_rhs(Ctx *c, bool with_soc) {
         hipLaunchKernelGGL(k_rhs_modes, dim3(with_soc ? 2 * g : g), dim3(RHS_NB), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
                            c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d);
     else
-        hipLaunchKernelGGL(k_rhs, dim3(g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale, c->prm.eps);
+        hipLaunchKernelGGL(k_rhs, dim3(with_soc ? g + g * (TILE_ELEMS / BLOCK) : g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale,
+                           c->prm.eps, g, c->prm.scale_z, c->prm.const_d);
     DOTS_HIP(hipGetLastError());
     return 0;
 }

@@ -684,6 +684,44 @@ __global__ __launch_bounds__(BLOCK) void k_time_modes_inv_gathered(Dev d, const 
     }
 }
 
+// Tiled forms of the two sharded transforms (same staging as k_time_modes_tile): the forward one stores only this
+// context's modes [a0, a0 + nloc) with the PCG view's pitch; the inverse one stages its tile from the gathered buffer.
+__global__ __launch_bounds__(BLOCK) void k_time_modes_fwd_sub_tile(Dev d, int a0, int nloc, int out_shift, const double *__restrict__ x,
+                                                                   double *__restrict__ y, int IC) {
+    extern __shared__ double tm_lds[];
+    const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+    double *Qs = tm_lds, *xs = tm_lds + IC * TP;
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    if (tile >= d.n_vtiles) return;
+    const int v0 = tile * d.VT;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int vl = e >> d.tp_shift, t = e & (TP - 1);
+        xs[vl * TPp + t] = (v0 + vl < d.V && t < n) ? x[idxV(d, v0 + vl, t)] : 0.0;
+    }
+    modes_from_tile<true>(d, d.Q, xs, Qs, IC, v0, y, out_shift, a0, nloc);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_time_modes_inv_gathered_tile(Dev d, const double *__restrict__ gathered, int nloc, int tpl_shift,
+                                                                        double *__restrict__ y, int IC) {
+    extern __shared__ double tm_lds[];
+    const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+    double *Qs = tm_lds, *xs = tm_lds + IC * TP;
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    if (tile >= d.n_vtiles) return;
+    const int v0 = tile * d.VT;
+    const int64_t rank_stride = (int64_t)d.V << tpl_shift;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int vl = e >> d.tp_shift, a = e & (TP - 1);
+        double val = 0.0;
+        if (v0 + vl < d.V && a < n) {
+            const int p = a / nloc, j = a - p * nloc;
+            val = gathered[p * rank_stride + ((int64_t)(v0 + vl) << tpl_shift) + j];
+        }
+        xs[vl * TPp + a] = val;
+    }
+    modes_from_tile<false>(d, d.Q, xs, Qs, IC, v0, y);
+}
+
 // Step 1 for the modes of this context.  Unsharded: also transforms back (phi is complete on return).
 // Sharded: the local mode-space solution stays in dcg.cg_x for the caller to exchange (cg_finish_sharded).
 template <bool MODAL>
@@ -700,7 +738,11 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats, bool defer_inverse) {
     const bool direct = MODAL && c->use_front && c->front.n_nodes > 0;   // no warm start, no mean removal needed
     if (sharded) {
         const int gs = 1024;   // grid-stride; k_cg_bmean sums exactly this many partial sums
-        hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.cg_b, g.cg_p0, owns_mode0 ? 1 : 0);
+        if (direct && time_modes_tile_ok(d))     // no mean removal with the direct solver: the tiled transform
+            hipLaunchKernelGGL(k_time_modes_fwd_sub_tile, dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, c->shard_begin, g.cg_ncol, g.tp_shift,
+                               d.cg_b, g.cg_p0, time_modes_chunk(d));
+        else
+            hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.cg_b, g.cg_p0, owns_mode0 ? 1 : 0);
         if (!direct) hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.phi, g.cg_x, 0);
         b = g.cg_p0;
         const double mean_scale = (singular && owns_mode0) ? 1.0 / d.V : 0.0;
@@ -751,8 +793,12 @@ int cg_solve(Ctx *c, dots_step_stats *stats, bool defer_inverse) {
 // phi from the mode-space solutions of all ranks (device buffer [n_ranks][V][local pitch])
 int cg_finish_sharded(Ctx *c, const double *gathered) {
     const Dev &d = c->d;
-    hipLaunchKernelGGL(k_time_modes_inv_gathered, dim3(xcd_grid(d.n_vtiles)), dim3(BLOCK), 0, c->stream, d, gathered, c->shard_stride,
-                       c->dcg.tp_shift, d.phi);
+    if (time_modes_tile_ok(d))
+        hipLaunchKernelGGL(k_time_modes_inv_gathered_tile, dim3(xcd_grid(d.n_vtiles)), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, gathered,
+                           c->shard_stride, c->dcg.tp_shift, d.phi, time_modes_chunk(d));
+    else
+        hipLaunchKernelGGL(k_time_modes_inv_gathered, dim3(xcd_grid(d.n_vtiles)), dim3(BLOCK), 0, c->stream, d, gathered, c->shard_stride,
+                           c->dcg.tp_shift, d.phi);
     DOTS_HIP(hipGetLastError());
     return 0;
 }
