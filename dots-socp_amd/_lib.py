@@ -17,7 +17,8 @@ ARRAY_IDS = {
     "mu": 7, "E": 8, "beta_fst": 9, "beta_mid": 10, "beta_end": 11,
 }
 LAP_SOLVERS = {"spacetime_pcg": 0, "modal_pcg": 1}
-PHASES = {"laplacian": 0, "soc_projection": 1, "q_lambda_mult": 2}
+PHASES = {"laplacian": 0, "soc_projection": 1, "q_lambda_mult": 2, "q_lambda": 3}
+STEP_SKIP_Z_MID, STEP_PALM = 1, 2
 OPERATORS = {
     "grad_time": 0, "div_time": 1, "grad_space": 2, "div_space": 3, "decouple": 4,
     "decouple_adjoint": 5, "time_avg_adjoint": 6, "laplacian_apply": 7,

@@ -101,7 +101,9 @@ class ErrorCondition:
         try:
             self.last = list(self.fn())
             return bool(self.last[0] < self.tol)
-        except Exception as exc:  # the reference swallows errors and reports inf
+        except (ArithmeticError, ValueError, TypeError) as exc:
+            # the reference swallows errors of the evaluation and reports inf (condition_validator.py:140-150);
+            # a device / state error of the library (HipLibraryError, a RuntimeError) is NOT "not converged": it propagates
             logger.error("Error in condition %r: %s", self.name, exc)
             self.last = [float("inf"), float("inf")]
             return False

@@ -241,8 +241,15 @@ static int check(dots_ctx *ctx) {
 }
 
 // first half of an iteration: right-hand side + solve (for this context's modes)
+static int palm_step0(Ctx *c) {
+    if (!c->step_palm) return 0;
+    if (c->zmid_stale) { set_error("step: DOTS_STEP_PALM needs z_mid of the previous iteration in memory"); return DOTS_ERR_STATE; }
+    return launch_q_lambda_only(c);
+}
+
 static int run_iteration_begin(Ctx *c, dots_step_stats *st) {
     int rc;
+    if ((rc = palm_step0(c))) return rc;
     if (!st) {   // enqueue only; the cone projection rides in the right-hand-side launch (run_iteration_end then skips it)
         c->soc_in_begin = c->soc_with_rhs;
         if ((rc = launch_rhs(c, c->soc_in_begin != 0))) return rc;
@@ -290,6 +297,7 @@ static int run_iteration_end(Ctx *c, const double *gathered, dots_step_stats *st
 
 static int run_iteration(Ctx *c, dots_step_stats *st) {
     int rc;
+    if ((rc = palm_step0(c))) return rc;
     if (!st) {   // asynchronous: enqueue only (the direct solver needs no host round trip); nothing is timed
         c->zmid_stale = c->step_skip_zmid;
         if (rhs_takes_soc(c)) {   // [right-hand side + projection] -> sweeps -> inverse transform -> steps 2+3
@@ -521,8 +529,10 @@ int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
 int dots_step_flags(dots_ctx *c, uint32_t flags) {
     int rc = check(c);
     if (rc) return rc;
-    if (flags & ~(uint32_t)DOTS_STEP_SKIP_Z_MID) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
+    if (flags & ~(uint32_t)(DOTS_STEP_SKIP_Z_MID | DOTS_STEP_PALM)) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
+    if ((flags & DOTS_STEP_SKIP_Z_MID) && (flags & DOTS_STEP_PALM)) { set_error("step_flags: DOTS_STEP_PALM reads z_mid, it cannot be combined with DOTS_STEP_SKIP_Z_MID"); return DOTS_ERR_ARGUMENT; }
     c->step_skip_zmid = (flags & DOTS_STEP_SKIP_Z_MID) ? 1 : 0;
+    c->step_palm = (flags & DOTS_STEP_PALM) ? 1 : 0;
     return 0;
 }
 
@@ -538,6 +548,10 @@ int dots_run_phase(dots_ctx *c, int phase, dots_step_stats *stats) {
             break;
         case DOTS_PHASE_SOC_PROJECTION: rc = launch_soc_projection(c); c->zmid_stale = 0; break;
         case DOTS_PHASE_Q_LAMBDA_MULT: rc = launch_q_lambda_mult(c); break;
+        case DOTS_PHASE_Q_LAMBDA:
+            if (c->zmid_stale) { set_error("phase q_lambda: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
+            rc = launch_q_lambda_only(c);
+            break;
         default: set_error("unknown phase"); return DOTS_ERR_ARGUMENT;
     }
     if (rc) return rc;

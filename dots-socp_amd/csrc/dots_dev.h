@@ -149,6 +149,7 @@ struct Ctx;
 int launch_soc_projection(Ctx *c, int zmid_mode = 0, bool with_inverse = false);   // 0: write z_mid; 1: write only the cone multiplier; with_inverse: extra workgroups do the modes -> time transform of phi
 int launch_rhs(Ctx *c, bool with_soc = false);   // with_soc (only when rhs_takes_soc): the cone projection rides in the same launch
 int launch_q_lambda_mult(Ctx *c, int zmid_mode = 0);    // 0: read z_mid; 1: rebuild it from the multiplier and store it; 2: rebuild, do not store
+int launch_q_lambda_only(Ctx *c);                       // the (q, lambda_c) closed form alone (is_palm's step 0): z_mid is read from memory
 int launch_adjust_penalty(Ctx *c, double factor);
 int launch_scale_z(Ctx *c, double z_mul, double beta_mul, double sz_new);
 int launch_scale_array(Ctx *c, int array_id, double factor);
@@ -200,6 +201,7 @@ struct Ctx {
     int soc_with_rhs = 1;         // DOTS_SOC_WITH_RHS=0: keep the projection after the solve (A/B measurements)
     int soc_in_begin = 0;         // the projection of the current sharded iteration already ran in dots_step_begin
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
+    int step_palm = 0;            // dots_step_flags: every iteration opens with the (q, lambda_c) closed form (is_palm = True)
     int zmid_stale = 0;           // z_mid does not belong to the current iterate
     FrontDev front{};             // multifrontal factor (n_nodes == 0: none)
     int use_front = 0;

@@ -244,14 +244,9 @@ int launch_rhs(Ctx *c, bool with_soc) {
 // Every beta_mid entry is attached to the node whose B it is compared with, so the thread that
 // computes B[t] updates them without any exchange: z_mid and beta_mid are read once, beta_mid written once.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, double sz, double cd, double cr, double tau);
-
-__global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_vertex(Dev d, double sz, double cd, double cr, double tau) {
-    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
-    if (tile >= d.n_vtiles) return;
-    q_lambda_vertex_tile(d, tile, sz, cd, cr, tau);
-}
-
+// QONLY: only the (q, lambda_c) closed form (the reference's "Step 0" of is_palm = True, solver_socp.py:668-672):
+// A, B and lambda_c are written, no multiplier moves.
+template <bool QONLY>
 __device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, double sz, double cd, double cr, double tau) {
     const int v0 = tile * d.VT;
     const double a1 = sz * (1.0 + cr);
@@ -268,6 +263,7 @@ __device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, dou
         const double lc = cl * (memo - a);
         d.A[iv] = a;
         d.lam[iv] = lc;
+        if (QONLY) continue;
         d.mu[iv] = mu + tau * (dphi - a - lc);
         d.bf[iv] = bf + tau * (zf + sz * a - cd);
         d.be[iv] = be + tau * (ze - sz * a - cd);
@@ -278,12 +274,12 @@ __device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, dou
 // kernel: z = (lambda / D) * (D * (sz/sqrt3 * B_old - beta_mid))) and stored; 2: rebuilt, not stored.
 // Workgroups [0, nf8) do the triangle part; with VERTEX_TOO the vertex part (independent of it: different
 // arrays) rides in the same launch as workgroups [nf8, nf8 + nv8).
-template <int ZMODE>
+template <int ZMODE, bool QONLY = false>
 __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double sz, double tau, int nf8, double cd, double cr) {
     constexpr int SUB = TILE_ELEMS / BLOCK;     // one element per thread: a workgroup takes a quarter of a triangle tile
     if ((int)blockIdx.x >= nf8 * SUB) {
         const int vt = xcd_tile(blockIdx.x - nf8 * SUB, d.n_vtiles);
-        if (vt < d.n_vtiles) q_lambda_vertex_tile(d, vt, sz, cd, cr, tau);
+        if (vt < d.n_vtiles) q_lambda_vertex_tile<QONLY>(d, vt, sz, cd, cr, tau);
         return;
     }
     const int tile = xcd_tile(blockIdx.x % nf8, d.n_ftiles);
@@ -344,6 +340,7 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
         const double Eo = d.E[ie];
         const double Bn = (gx + Eo + sB * S) / ((t == 0 || t == d.T) ? diag_bd : diag_in);
         d.B[ie] = Bn;
+        if (QONLY) continue;
         d.E[ie] = Eo + tau * (gx - Bn);
         const double sBn = sB * Bn;
 #pragma unroll
@@ -352,6 +349,16 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
             if (t > 0) d.bm[idxM(d, f * 3 + k, 1, c, t - 1)] = b1[k] + tau * (z1[k] - sBn);
         }
     }
+}
+
+// Step 0 of is_palm = True: (A, B, lambda_c) from the current multipliers and the stored z_mid; nothing else moves.
+int launch_q_lambda_only(Ctx *c) {
+    const dots_params &p = c->prm;
+    const int nf8 = xcd_grid(c->d.n_ftiles), nv8 = xcd_grid(c->d.n_vtiles);
+    hipLaunchKernelGGL((k_q_lambda_mult_triangle<0, true>), dim3(nf8 * (TILE_ELEMS / BLOCK) + nv8), dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8,
+                       p.const_d, p.congestion * p.r);
+    DOTS_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_q_lambda_mult(Ctx *c, int zmid_mode) {

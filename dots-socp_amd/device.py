@@ -130,8 +130,9 @@ class DeviceProblem:
         _lib.check(self.lib.dots_step(self._h, int(n_iters), C.byref(st)), "dots_step")
         return st
 
-    def step_flags(self, skip_z_mid=False):
-        _lib.check(self.lib.dots_step_flags(self._h, 1 if skip_z_mid else 0), "dots_step_flags")
+    def step_flags(self, skip_z_mid=False, palm=False):
+        flags = (_lib.STEP_SKIP_Z_MID if skip_z_mid else 0) | (_lib.STEP_PALM if palm else 0)
+        _lib.check(self.lib.dots_step_flags(self._h, flags), "dots_step_flags")
 
     # ---- sharded iteration (multi-GPU): begin -> all-gather by the caller -> end
     def shard_elems(self):

@@ -145,11 +145,12 @@ class ShardedAlmSolver(AlmSolver):
         self._send = torch.zeros(elems, dtype=torch.float64, device=dev)
         self._recv = torch.zeros(elems * comm.size, dtype=torch.float64, device=dev)
         self.comm_seconds = 0.0
+        self.clock_exchanges = 0
 
     def _device_step(self, quiet=False):
         import torch
 
-        self.dev.step_flags(skip_z_mid=quiet)
+        self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm)
         on_device = self._send.is_cuda and self.direct
         if on_device:
             # no host wait anywhere: the context's stream and the stream the collective runs on are ordered by events
@@ -172,10 +173,14 @@ class ShardedAlmSolver(AlmSolver):
         self.run_history.add_time("Exchange (all-gather of the mode-space solution)", 0.0)
         self.run_history.steps_time["Exchange (all-gather of the mode-space solution)"] = self.comm_seconds
 
-    def _time_is_up(self):
-        # every rank must leave the loop on the same iteration: the decision is shared
-        if self.time_limit is None or self.time_limit > 1e8:
+    def _time_is_up(self, reads_back=True):
+        """Every rank must leave the loop on the same iteration, so the clock decision is shared (one flag
+        all-reduce) -- but only on iterations that synchronise with the host anyway (KKT evaluation or penalty
+        update: at least every 37th, control.AdaptiveValidator): enqueue-only iterations see no collective and no
+        host wait because of a finite time_limit."""
+        if not reads_back or self.time_limit is None or self.time_limit > 1e8:
             return False
+        self.clock_exchanges += 1
         return self.comm.any_flag((time.perf_counter() - self.start_time) > self.time_limit)
 
 

@@ -64,13 +64,14 @@ class AlmSolver:
 
     def __init__(self, n_time, geometry, congestion=0.0, nit=1000, eps=0.0, tol=1e-4, tau=1.90, is_z_scaling=True,
                  is_constant_scaling=False, check_kkt_step_by_step=False, init_solution=None, tol_checkpoints=None,
-                 time_limit=1000, lap_solver="modal_direct", cg_tol=DEFAULT_CG_TOL, cg_max_iter=20000, device=0, reorder=True,
+                 time_limit=1000, is_palm=False, lap_solver="modal_direct", cg_tol=DEFAULT_CG_TOL, cg_max_iter=20000, device=0, reorder=True,
                  preconditioner="multigrid", mg_coarsest=256, mode_shard=None, nd_leaf=16):
         self.tol_checkpoints = _validate_checkpoints(tol_checkpoints, tol)
         self.checkpoint_solutions = []
         self.n_time, self.nit, self.tol, self.time_limit = int(n_time), int(nit), tol, time_limit
         self.is_z_scaling, self.is_constant_scaling = is_z_scaling, is_constant_scaling
         self.check_kkt_step_by_step = check_kkt_step_by_step
+        self.is_palm = bool(is_palm)      # an extra (q, lambda_c) solve opens every iteration (solver_socp.py:668-672)
         self.direct = direct = lap_solver == "modal_direct"
         self.untimed_steps = 0
         if direct and reorder is True:
@@ -230,14 +231,17 @@ class AlmSolver:
 
         ``quiet``: nothing is read back after this iteration (no KKT evaluation, not the last one): z_mid
         need not be stored, and with the direct solver the host does not wait for the device either."""
-        self.dev.step_flags(skip_z_mid=quiet)
+        # is_palm's step 0 reads z_mid of the previous iteration: it is stored every iteration then
+        self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm)
         if quiet and self.direct:
             self.dev.step(1, wait=False)
             self.untimed_steps += 1
         else:
             self._account(self.dev.step(1))
 
-    def _time_is_up(self):
+    def _time_is_up(self, reads_back=True):
+        """``reads_back``: this iteration synchronises with the host anyway (the multi-GPU driver only shares the
+        clock decision on those iterations)."""
         return (time.perf_counter() - self.start_time) > self.time_limit
 
     def _account(self, st):
@@ -261,13 +265,13 @@ class AlmSolver:
             if rescale_z > 1.25:
                 self.scale_variable_z(rescale_z, msg=f"Rescale z at iteration {it}")
 
-        # The reference looks at the clock after the step (:727); here before it, so that it is known in
-        # advance whether this iteration's results are read back (a wall-clock limit has no parity to keep).
-        is_time_used_up = self._time_is_up()
+        # The reference looks at the clock after the step (:725); here before it, so that it is known in advance whether
+        # this iteration's results are read back (a wall-clock limit has no parity to keep).
         validator = self.kkt_validator
-        quiet = not (is_time_used_up or self.check_kkt_step_by_step or it + 1 >= self.nit or params.peek_adjust(it)
-                     or validator.will_validate_next()
-                     or (self.is_constant_scaling and params.is_to_scale(it + 1)))   # the next iteration opens with norms of z
+        reads_back = (self.check_kkt_step_by_step or it + 1 >= self.nit or params.peek_adjust(it) or validator.will_validate_next()
+                      or (self.is_constant_scaling and params.is_to_scale(it + 1)))   # the next iteration opens with norms of z
+        is_time_used_up = self._time_is_up(reads_back)
+        quiet = not (is_time_used_up or reads_back)
         self._device_step(quiet)                                                # steps 1-3 (:674-722)
 
         adjust = params.is_to_adjust(it) or is_time_used_up
@@ -375,11 +379,9 @@ def solver_socp(
     ``checkpoints``; ``run_history`` is a :class:`RunningHistory`.
     ``is_multi_threads`` is accepted and ignored (the GPU path has no host threads to split).
     """
-    if is_palm:
-        raise NotImplementedError("is_palm=True (the plain-ALM variant) is outside the scoped hot path")
     alm = AlmSolver(n_time, geometry, congestion=congestion, nit=nit, eps=eps, tol=tol, tau=tau, is_z_scaling=is_z_scaling,
                     is_constant_scaling=is_constant_scaling, check_kkt_step_by_step=check_kkt_step_by_step,
-                    init_solution=init_solution, tol_checkpoints=tol_checkpoints, time_limit=time_limit,
+                    init_solution=init_solution, tol_checkpoints=tol_checkpoints, time_limit=time_limit, is_palm=is_palm,
                     lap_solver=lap_solver, cg_tol=cg_tol, cg_max_iter=cg_max_iter, device=device, reorder=reorder,
                     preconditioner=preconditioner, mg_coarsest=mg_coarsest, nd_leaf=nd_leaf)
     try:

@@ -164,6 +164,10 @@ int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
  * flag (or an upload / the projection phase) has produced it again.  The host driver sets it on the iterations
  * after which neither KKT residuals nor the solution are read (solver_socp.py's lazy validator, :766-788). */
 #define DOTS_STEP_SKIP_Z_MID 1u
+/* DOTS_STEP_PALM: every iteration opens with the (q, lambda_c) closed form alone ("Step 0" of is_palm = True,
+ * solver_socp.py:668-672: A, B, lambda_c from the current multipliers, the stored z_mid and grad(phi) of the previous
+ * iteration).  It reads z_mid from memory, so it cannot be combined with DOTS_STEP_SKIP_Z_MID (DOTS_ERR_ARGUMENT). */
+#define DOTS_STEP_PALM 2u
 int dots_step_flags(dots_ctx *ctx, uint32_t flags);
 
 /* One ALM iteration split around the only exchange of the multi-GPU path (mode-sharded solve):
@@ -189,7 +193,8 @@ int64_t dots_shard_elems(dots_ctx *ctx);   /* doubles one rank contributes: V * 
 enum dots_phase {
     DOTS_PHASE_LAPLACIAN = 0,        /* vanilla_solve_laplacian  solver_socp.py:976-986 + laplacian_inverse_socp.py:52-61 */
     DOTS_PHASE_SOC_PROJECTION = 1,   /* vanilla_solve_proj_soc   solver_socp.py:988-1042 */
-    DOTS_PHASE_Q_LAMBDA_MULT = 2     /* grad_time/grad_space + vanilla_solve_q_lambda :709-714,1044-1065 and the multiplier update :716-722 */
+    DOTS_PHASE_Q_LAMBDA_MULT = 2,    /* grad_time/grad_space + vanilla_solve_q_lambda :709-714,1044-1065 and the multiplier update :716-722 */
+    DOTS_PHASE_Q_LAMBDA = 3          /* vanilla_solve_q_lambda alone (is_palm's step 0, :668-672): no multiplier moves */
 };
 int dots_run_phase(dots_ctx *ctx, int phase, dots_step_stats *stats);
 

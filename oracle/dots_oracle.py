@@ -578,10 +578,13 @@ class OracleSolver:
         self.z_end[:] = lam * w_end
 
     # -- a8  (q, lambda_c) closed form (solver_socp.py:709-714, :1044-1065)
-    def step_q_lambda(self):
+    def step_q_lambda(self, refresh_gradients=True):
+        """``refresh_gradients=False``: is_palm's step 0 (solver_socp.py:668-672) -- the closed form with dt_phi / dx_phi
+        as they stand (initially the gradients of the initial phi, :253-255)."""
         c, r, sz = self.congestion, self.r, self.sz
-        self.dt_phi = grad_time(self.h, self.phi)
-        self.dx_phi = grad_space(self.G, self.F, self.phi)
+        if refresh_gradients:
+            self.dt_phi = grad_time(self.h, self.phi)
+            self.dx_phi = grad_space(self.G, self.F, self.phi)
         a1 = sz * (1.0 + c * r)
         a2 = 1.0 + 2.0 * sz * a1
         memo_a = self.dt_phi + self.mu
@@ -753,12 +756,9 @@ def solver_socp(n_time, geometry, congestion=0.0, nit=1000, eps=0.0, tol=1e-4, t
                 trace=None):
     """Same contract as the reference's solver_socp (solver_socp.py:25-41, :855-871).
 
-    ``is_palm`` is not restated (it is not on the scoped path; the reference's
-    default is False) and raises.  ``trace``: optional list that receives one dict
-    per iteration (decisions taken), used by tests only.
+    ``is_palm``: an extra (q, lambda_c) solve opens every iteration (:668-672).  ``trace``: optional list that
+    receives one dict per iteration (decisions taken), used by tests only.
     """
-    if is_palm:
-        raise NotImplementedError("oracle restates the default is_palm=False path only")
     checkpoints = []
     if tol_checkpoints is not None:  # :85-94
         if not isinstance(tol_checkpoints, list) or not tol_checkpoints:
@@ -771,6 +771,8 @@ def solver_socp(n_time, geometry, congestion=0.0, nit=1000, eps=0.0, tol=1e-4, t
         tol_checkpoints = sorted(tol_checkpoints, reverse=True)
 
     s = OracleSolver(n_time, geometry, congestion=congestion, eps=eps, tau=tau, init_solution=init_solution)
+    if is_palm:                                                     # :253-255
+        s.dt_phi, s.dx_phi = grad_time(s.h, s.phi), grad_space(s.G, s.F, s.phi)
     hist = History(nit)
     policy = PenaltyPolicy()
     stop_set, prim_pos, dual_pos = [0, 2, 4, 5], [0, 1], [2, 3]   # :299-301
@@ -800,6 +802,9 @@ def solver_socp(n_time, geometry, congestion=0.0, nit=1000, eps=0.0, tol=1e-4, t
             if rescale > 1.25:
                 s.scale_z(rescale)
 
+        if is_palm:                                                 # :668-672
+            with hist.timer("Step 0 (Q & Lambda)"):
+                s.step_q_lambda(refresh_gradients=False)
         with hist.timer("Step 1-1 (Laplacian)"):
             s.step_laplacian()
         with hist.timer("Step 1-2 (SOC-Projection)"):

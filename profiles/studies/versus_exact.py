@@ -23,8 +23,8 @@ for n, T in ((20, 31), (40, 31), (80, 63), (160, 63), (240, 127)):
     cost = hist.history["Transportation cost"][-1] / scale ** 2
     tt = np.linspace(0.0, 1.0, sol["mu"].shape[0])           # time-centred grid: the T + 1 nodes
     exact = evaluate.plane_exact_transportation(tt, geom["vertices"] / scale, geom["area_vertices"])
-    err = evaluate.compare_with_exact_transportation(sol["mu"], exact, geom["area_vertices"])
-    mass, _ = evaluate.check_mass_conservation(sol["mu"])
+    err = evaluate.compare_with_exact_transportation(sol["mu"], exact, geom)
+    mass = evaluate.check_mass_conservation(sol["mu"])
     neg, _ = evaluate.check_negative_mass(sol["mu"])
     print(f"{n:5d} {geom['vertices'].shape[0]:7d} {T:4d} {int(hist.kkt_iteration[-1]) + 1:6d} {sec:7.2f} {cost:12.8f} {cost - 0.04:10.2e} "
           f"{err['l1']:9.2e} {err['l2']:9.2e} {err['linf']:9.2e} {mass:9.2e} {neg:9.2e}", flush=True)

@@ -5,12 +5,14 @@ copied) on small seeded inputs and stores inputs + outputs as ``*.npz`` next to 
 file.  The fixtures are data; they travel to the GPU box, the reference does not.
 
     python tests/golden/make_golden.py            # (re)generate everything
-    python tests/golden/make_golden.py ops runs   # subsets: ops | runs | full
+    python tests/golden/make_golden.py ops runs   # subsets: ops | runs | full | palm | f1 | settings
 
 Fixture families
     ops_<mesh>.npz    per-function input/output vectors
     run_<case>.npz    solver_socp runs: k-iteration states, KKT trajectories, lazy-schedule
-                      histories, stopping iteration, cost, objective (rows a1, a11-a14, a16)
+                      histories, stopping iteration, cost, objective (rows a1, a11-a14, a16); *_palm_*: is_palm=True
+    f1_<case>.npz     outputs of the solver / solver_raw decorators and of utils/evaluate_solution.py (row f1)
+    settings_get_mu.npz   get_mu of every data/settings/*.py on one synthetic mesh (row f3)
 """
 from __future__ import annotations
 
@@ -240,14 +242,119 @@ def make_runs(ref, full, small=True):
         save_run(name, g, T, kw, sol, hist, keep, *rest)
 
 
+# --------------------------------------------------------------------------- #
+# the steps either side of the path and the is_palm variant
+# --------------------------------------------------------------------------- #
+def quiet(fn, *a, **kw):
+    buf = io.StringIO()
+    logging.disable(logging.CRITICAL)
+    try:
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(buf):
+            return fn(*a, **kw)
+    finally:
+        logging.disable(logging.NOTSET)
+
+
+def make_palm(ref):
+    """solver_socp(is_palm=True) (solver_socp.py:668-672): an extra (q, lambda) solve ahead of step 1."""
+    tm = tiny_meshes(ref)
+    g_ico1, _ = geometry_for(ref, *tm["ico1"])
+    g_ico2, _ = geometry_for(ref, *meshes.icosphere(2))
+    for name, g, T, kw, keep in (
+        ("ico1_T6_palm_k12_steps", g_ico1, 6, dict(nit=12, tol=1e-12, is_palm=True, check_kkt_step_by_step=True), ALL_STATE),
+        ("ico1_T6_palm_cong_k40_lazy", g_ico1, 6, dict(nit=40, tol=1e-12, is_palm=True, congestion=0.05), ALL_STATE),
+        ("ico2_T15_palm_tol1e-3", g_ico2, 15, dict(nit=3000, tol=1e-3, is_palm=True), SMALL_STATE),
+    ):
+        sol, hist = run_reference(ref, g, T, **kw)
+        save_run(name, g, T, kw, sol, hist, keep)
+
+
+def make_f1(ref):
+    """Outputs of the reference's solver / solver_raw decorators (socp/solver_decorator.py:10-72, utils/type.py:48-65)
+    and of utils/evaluate_solution.py:7-58 on recorded solutions."""
+    E = ref.evaluate_solution
+    g_ico2, _ = geometry_for(ref, *meshes.icosphere(2))
+    g_tor, _ = geometry_for(ref, *ref_tiny(ref)["torus8x6"])
+    for name, g, T, kw in (
+        ("ico2_T15_ckpt", g_ico2, 15, dict(nit=3000, tol=1e-3, tol_checkpoints=[1e-1, 1e-2])),
+        ("torus_T7_cong", g_tor, 7, dict(nit=400, tol=1e-3, congestion=0.05)),
+    ):
+        out = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"], n_time=np.array(T))
+        for k, val in kw.items():
+            out[f"kw_{k}"] = np.array(val, dtype=np.float64) if k == "tol_checkpoints" else np.array(val)
+        for tag, fn in (("raw", ref.decorator.solver_raw), ("center", ref.decorator.solver)):
+            kw_run = {k: (list(v) if k == "tol_checkpoints" else v) for k, v in kw.items()}
+            sol, hist = quiet(fn, T, dict(g), **kw_run)
+            out[f"{tag}_mu"], out[f"{tag}_E"] = sol["mu"], sol["E"]
+            out[f"{tag}_last_iteration"] = np.array(int(hist.kkt_iteration[-1]))
+            if sol.get("checkpoints"):
+                out[f"{tag}_ckpt_mu"] = np.stack([c["mu"] for c in sol["checkpoints"]])
+                out[f"{tag}_ckpt_E"] = np.stack([c["E"] for c in sol["checkpoints"]])
+                out[f"{tag}_ckpt_iteration"] = np.array([c["iteration"] for c in sol["checkpoints"]])
+            # the three checks of evaluate_solution.py on this solution; "exact" = a seeded perturbation of it
+            mu = sol["mu"]
+            rng = np.random.default_rng(7)
+            exact = mu * (1.0 + 0.05 * rng.standard_normal(mu.shape)) + 1e-4 * rng.standard_normal(mu.shape)
+            out[f"{tag}_exact"] = exact
+            out[f"{tag}_mass_conservation"] = np.array(quiet(E.check_mass_conservation, mu, verbose=False))
+            neg, layers = quiet(E.check_negative_mass, mu, verbose=False)
+            out[f"{tag}_negative_mass"], out[f"{tag}_negative_mass_layers"] = np.array(neg), layers
+            err = quiet(E.compare_with_exact_transportation, mu, exact, g, verbose=False)
+            out[f"{tag}_versus_exact"] = np.array([err["l1"], err["l2"], err["linf"]])
+        np.savez_compressed(os.path.join(HERE, f"f1_{name}.npz"), **out)
+        print("wrote", f"f1_{name}.npz")
+    # the plane example's analytic transport (data/settings/plane.py:29-46) on the reference's own plane mesh
+    v, t, _ = ref.plane_mesh.generate_mesh(6)
+    t = np.asarray(t)
+    av = meshes.vertex_areas(v.shape[0], t, meshes.triangle_areas(v, t))
+    tt = np.linspace(0.0, 1.0, 5)
+    np.savez_compressed(os.path.join(HERE, "f1_plane_exact.npz"), vertices=v, triangles=t, area_vertices=av, t_array=tt,
+                        exact=ref.plane_setting.get_exact_transportation(tt, v, av))
+    print("wrote f1_plane_exact.npz")
+
+
+def ref_tiny(ref):
+    return tiny_meshes(ref)
+
+
+def make_settings(ref):
+    """get_mu of every data/settings/*.py on ONE synthetic mesh with enough vertices for the fixed
+    vertex indices the recipes use (the packaged .off meshes are LFS pointers): torus 130 x 100 scaled to [-1.2, 1.2]."""
+    v, t = meshes.torus(130, 100)
+    v = 1.2 * v / np.abs(v).max()
+    av = meshes.vertex_areas(v.shape[0], t, meshes.triangle_areas(v, t))
+    out = dict(vertices=v, triangles=t, area_vertices=av)
+    for name, mod in sorted(ref.settings.items()):
+        if name == "sphere":      # reads data_mu/*.txt: no recipe to restate
+            continue
+        mu0, mu1 = mod.get_mu(av.copy(), v.copy())
+        out[f"{name}_mu0"], out[f"{name}_mu1"] = np.asarray(mu0, float), np.asarray(mu1, float)
+    # a second mesh (sphere of radius 1.45) for the two recipes whose second density has no mass on the torus
+    v2, t2 = meshes.icosphere(4, radius=1.45)
+    av2 = meshes.vertex_areas(v2.shape[0], t2, meshes.triangle_areas(v2, t2))
+    out.update(sphere_vertices=v2, sphere_triangles=t2, sphere_area_vertices=av2)
+    for name in ("eight", "knots_3"):
+        mu0, mu1 = ref.settings[name].get_mu(av2.copy(), v2.copy())
+        assert mu0.sum() > 0 and mu1.sum() > 0, name
+        out[f"sphere_{name}_mu0"], out[f"sphere_{name}_mu1"] = np.asarray(mu0, float), np.asarray(mu1, float)
+    np.savez_compressed(os.path.join(HERE, "settings_get_mu.npz"), **out)
+    print("wrote settings_get_mu.npz", len(out) // 2 - 1, "settings")
+
+
 def main(argv):
-    what = set(argv) or {"ops", "runs", "full"}
+    what = set(argv) or {"ops", "runs", "full", "palm", "f1", "settings"}
     ref = ref_shim.load_reference()
     if "ops" in what:
         for i, (name, (v, t)) in enumerate(tiny_meshes(ref).items()):
             make_ops(ref, name, v, t, n_time=(4, 6, 5)[i], seed=100 + i)
     if "runs" in what or "full" in what:
         make_runs(ref, full="full" in what, small="runs" in what)
+    if "palm" in what:
+        make_palm(ref)
+    if "f1" in what:
+        make_f1(ref)
+    if "settings" in what:
+        make_settings(ref)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,9 @@ WORKLOADS = {   # same table as bench.py
     "knot": dict(example="knot", kw={}, n_time=31, congestion=0.0, tol=1e-3),
     "knot63": dict(example="knot", kw={}, n_time=63, congestion=0.1, tol=1e-3),
     "torus100k": dict(example="torus", kw=dict(nu=400, nv=250), n_time=31, congestion=0.0, tol=1e-3),
+    # BASELINE configs[4] stand-in at its full size; the reference needs ~1 min per iteration there, so the run is
+    # TRUNCATED: the first `nit` iterations with every KKT residual and the objective recorded each iteration
+    "torus65k_T127": dict(example="torus", kw=dict(nu=360, nv=180), n_time=127, congestion=0.0, tol=1e-5, nit=10, check_kkt_step_by_step=True),
 }
 
 
@@ -50,12 +53,14 @@ def main(argv):
         wl = WORKLOADS[name]
         geom, scale = meshes.example(wl["example"], **wl["kw"])
         t0 = time.time()
-        sol, hist = solve(wl["n_time"], geom, nit=20000, tol=wl["tol"], congestion=wl["congestion"], time_limit=1e9)
+        extra = {k: wl[k] for k in ("check_kkt_step_by_step",) if k in wl}
+        sol, hist = solve(wl["n_time"], geom, nit=wl.get("nit", 20000), tol=wl["tol"], congestion=wl["congestion"], time_limit=1e9, **extra)
         sec = time.time() - t0
         mu = np.asarray(sol["mu"])
         out = dict(
             source=np.array(who), n_time=np.array(wl["n_time"]), tol=np.array(wl["tol"]), congestion=np.array(wl["congestion"]),
-            scale_factor=np.array(scale), seconds=np.array(sec),
+            scale_factor=np.array(scale), seconds=np.array(sec), nit=np.array(wl.get("nit", 20000)),
+            check_kkt_step_by_step=np.array(bool(wl.get("check_kkt_step_by_step", False))),
             vertices_checksum=np.array([geom["vertices"].sum(), np.abs(geom["vertices"]).sum(), float(geom["triangles"].sum())]),
             mu0_checksum=np.array([np.dot(geom["mu0"], np.arange(geom["mu0"].size)), np.dot(geom["mu1"], np.arange(geom["mu1"].size))]),
             last_iteration=np.array(int(hist.kkt_iteration[-1])),

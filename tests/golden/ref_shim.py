@@ -84,6 +84,11 @@ def _patch_admm_tools(src: str) -> str:
     return re.sub(r'self\._separate_symbol\("([^"]*)"\)', r"self._separate_symbol('\1')", src)
 
 
+def _patch_evaluate_solution(src: str) -> str:
+    # f"... {error_transportation["l1"]:.2e}" -> single quotes inside the f-string (log text only)
+    return re.sub(r'error_transportation\["(l1|l2|linf)"\]', r"error_transportation['\1']", src)
+
+
 _loaded = None
 
 
@@ -128,6 +133,18 @@ def load_reference():
         cv = importlib.import_module("dot_surface_socp.utils.condition_validator")
         cvw = importlib.import_module("dot_surface_socp.utils.condition_validator_wrapper")
         typ = importlib.import_module("dot_surface_socp.utils.type")
+        # the steps either side of the path: decorators, solution checks, example settings
+        decorator = importlib.import_module("dot_surface_socp.socp.solver_decorator")
+        evaluate = _load_from_text(
+            "dot_surface_socp.utils.evaluate_solution",
+            os.path.join(pkg, "utils", "evaluate_solution.py"),
+            patch=_patch_evaluate_solution,
+        )
+        _register_namespace("dot_surface_socp.data.settings", os.path.join(pkg, "data", "settings"))
+        settings = {}
+        for fn in sorted(os.listdir(os.path.join(pkg, "data", "settings"))):
+            if fn.endswith(".py") and fn != "__init__.py":
+                settings[fn[:-3]] = importlib.import_module("dot_surface_socp.data.settings." + fn[:-3])
     finally:
         os.chdir(cwd)
 
@@ -153,6 +170,9 @@ def load_reference():
         data_util=data_util,
         plane_mesh=plane_mesh,
         plane_setting=plane_setting,
+        decorator=decorator,
+        evaluate_solution=evaluate,
+        settings=settings,
     )
     _loaded = ns
     return ns

@@ -55,6 +55,31 @@ def test_device_factor_matches_host_factor_and_pcg(mesh, kw, T, eps):
     assert rel(out["dev_nd"], out["pcg"]) < 1e-8
 
 
+def test_indefinite_operator_is_reported():
+    """A non-positive pivot of the device factorisation (kernels_factor.hip: bad_pivot) comes back as
+    DOTS_ERR_ARGUMENT with its message, leaves no factor installed and releases the factor's allocations.
+    Trigger: a stiffness matrix with a positive diagonal (dots_create accepts it) whose off-diagonal entries are
+    tripled, so K + sigma M is indefinite for the low modes."""
+    from dots_socp_amd import _lib
+    from dots_socp_amd.device import DeviceProblem
+    from dots_socp_amd.geometry import build_plan
+
+    geom, _ = meshes.example("sphere", level=3)
+    plan = build_plan(7, geom, reorder="nd")
+    rows = np.repeat(np.arange(plan.n_vertices), np.diff(plan.lap_rowptr))
+    plan.lap_val = np.where(plan.lap_col == rows, plan.lap_val, 3.0 * plan.lap_val)
+    dev = DeviceProblem(7, geom, lap_solver="modal_pcg", plan=plan)
+    with pytest.raises(_lib.HipLibraryError, match="pivot"):
+        dev.setup_frontal(eps=0.0)
+    with pytest.raises(_lib.HipLibraryError, match="no factor"):
+        dev.enable_frontal(True)
+    # the context is still usable with a sound factor source: a second, healthy context on the same process
+    dev.close()
+    dev = DeviceProblem(7, geom, lap_solver="modal_pcg", reorder="nd")
+    assert dev.setup_frontal(eps=0.0)["levels"] >= 3
+    dev.close()
+
+
 def test_direct_solver_is_deterministic_and_exact():
     """Two contexts give bit-identical phi; K phi reproduces the right-hand side to rounding."""
     geom, _ = meshes.example("sphere", level=4)

@@ -188,7 +188,7 @@ def test_kkt_objective_norms_a10_a11_a12(fname, congestion):
     dev.close()
 
 
-@pytest.mark.parametrize("fname", OPS[:1])
+@pytest.mark.parametrize("fname", OPS)
 def test_scaling_tools_a13(fname):
     s, dev = make_pair(golden(fname))
     s.adjust_penalty(1.35)

@@ -114,6 +114,29 @@ def test_decorators_and_argument_errors():
             solver_raw(8, geom, nit=1, tol=1e-3, tol_checkpoints=bad)
 
 
+@pytest.mark.parametrize("fname", ["f1_ico2_T15_ckpt.npz", "f1_torus_T7_cong.npz"])
+def test_solver_and_solver_raw_match_the_reference_decorators(fname):
+    """outputs of the reference's ``solver_raw`` / ``solver`` (socp/solver_decorator.py:10-72,
+    utils/type.py:48-65: masses, fluxes, time-centred grid, converted checkpoints) recorded by make_golden.py f1."""
+    from dots_socp_amd.socp import solver, solver_raw
+
+    g = golden(fname)
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    kw = {k[3:]: (g[k].tolist() if g[k].ndim else g[k].item()) for k in g.files if k.startswith("kw_")}
+    for tag, fn in (("raw", solver_raw), ("center", solver)):
+        kw_run = {k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()}
+        sol, hist = fn(int(g["n_time"]), dict(geom), **kw_run)
+        assert int(hist.kkt_iteration[-1]) == int(g[f"{tag}_last_iteration"])
+        assert sol["mu"].shape == g[f"{tag}_mu"].shape and sol["E"].shape == g[f"{tag}_E"].shape
+        assert rel(sol["mu"], g[f"{tag}_mu"]) < 1e-5 and rel(sol["E"], g[f"{tag}_E"]) < 1e-5
+        if f"{tag}_ckpt_mu" in g.files:
+            assert [c["iteration"] for c in sol["checkpoints"]] == g[f"{tag}_ckpt_iteration"].tolist()
+            assert rel(np.stack([c["mu"] for c in sol["checkpoints"]]), g[f"{tag}_ckpt_mu"]) < 1e-5
+            assert rel(np.stack([c["E"] for c in sol["checkpoints"]]), g[f"{tag}_ckpt_E"]) < 1e-5
+        else:
+            assert not sol.get("checkpoints")
+
+
 def test_warm_start_is_a_fixed_point():
     """Restarting from a converged solution (init_solution, solver_socp.py:239-250) stops at once."""
     from dots_socp_amd.socp import solver_socp
@@ -142,9 +165,9 @@ def test_plane_against_the_exact_transport():
     assert sol["mu"].shape == (T + 1, geom["vertices"].shape[0])      # time-centred grid: the T + 1 nodes
     tt = np.linspace(0.0, 1.0, T + 1)
     exact = evaluate.plane_exact_transportation(tt, geom["vertices"] / scale, geom["area_vertices"])
-    err = evaluate.compare_with_exact_transportation(sol["mu"], exact, geom["area_vertices"])
-    assert err["l1"] < 1e-2 and err["l2"] < 1e-2 and err["linf"] < 5e-2
-    assert evaluate.check_mass_conservation(sol["mu"])[0] < 1e-4
+    err = evaluate.compare_with_exact_transportation(sol["mu"], exact, geom)
+    assert err["l1"] < 2e-2 and err["l2"] < 1e-2 and err["linf"] < 5e-2      # the reference's norms (time step inside)
+    assert evaluate.check_mass_conservation(sol["mu"]) < 1e-4
     assert evaluate.check_negative_mass(sol["mu"])[0] < 1e-5
 
 
