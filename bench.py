@@ -1,22 +1,33 @@
 #!/usr/bin/env python
 """bench.py -- ALM iterations per second of the DOTs-SOCP hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sphere10k|knot|torus100k|plane20]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload knot|sphere10k|knot63|torus100k|torus65k_T127|plane20]
 
-One "step" is one full pass of the solver's main loop (reference solver_socp.py:656-823): steps 1-3
-(Laplacian solve to the parity tolerance, cone projection, (q, lambda) + multiplier update) plus
-whatever KKT evaluation / penalty update the lazy schedule puts on that iteration.  All state is
-resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line.
+One "step" is one full pass of the solver's main loop (reference solver_socp.py:656-823): steps 1-3 (Laplacian solve,
+cone projection, (q, lambda) + multiplier update) plus whatever KKT evaluation / penalty update the reference's lazy
+schedule puts on that iteration.  All state is resident in HBM before the timed region starts.  Rank 0 prints ONE
+JSON line.
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the Laplacian solve is sharded over the
-T+1 time modes with one all-gather per iteration; see dots-socp_amd/distributed.py.  `value` is whole-job iterations/s (the iterations are
-collective: every rank advances the same ALM iteration).
+* ``value`` / ``ms_per_step``: the workload BASELINE.json's metric is quoted on (``knot``: the knots_5 stand-in, T=31),
+  W untimed + exactly K timed iterations as the driver asks.
+* ``steady_state``: the same solver run on to iteration 100, then 200 iterations timed (independent of K / W: the first
+  25 iterations are dense in penalty updates and KKT checks, admm_tools.py:43-48).
+* ``configs``: all five BASELINE.json configurations (N = 1): steady-state it/s, ms/step, time to tol, roofline.
+* ``roofline``: the dominant kernels (the two triangular sweeps of the direct solve), hipEvent-timed on the context's
+  own stream; ``whole_iteration`` counts the bytes the implemented iteration moves (no z_mid traffic on the
+  iterations that do not materialise it).
+* ``cpu_baseline``: the numpy/SuperLU oracle on the same workload on this host's cores (bounded sample).
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the iteration is sharded (dots-socp_amd/distributed.py);
+``value`` is whole-job iterations/s (the iterations are collective: every rank advances the same ALM iteration),
+"scaling": "strong".
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,19 +37,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 WORKLOADS = {
-    # BASELINE.json configs[1]: "sphere mesh ~10k vertices, ntime=31, 1xMI355X, congestion=0.0"
-    "sphere10k": dict(example="sphere", kw=dict(level=5), n_time=31, congestion=0.0, tol=1e-3),
-    # configs[0] stand-in: knots_5-like tube, ntime=31
-    "knot": dict(example="knot", kw={}, n_time=31, congestion=0.0, tol=1e-3),
-    # configs[3]: ~100k-vertex torus, ntime=31
-    "torus100k": dict(example="torus", kw=dict(nu=400, nv=250), n_time=31, congestion=0.0, tol=1e-3),
+    # configs[0] stand-in, the configuration the metric is quoted on: knots_5-like tube, ntime=31, tol 1e-3
+    "knot": dict(example="knot", kw={}, n_time=31, congestion=0.0, tol=1e-3, config=0),
+    # configs[1]: "sphere mesh ~10k vertices, ntime=31, 1xMI355X, congestion=0.0"
+    "sphere10k": dict(example="sphere", kw=dict(level=5), n_time=31, congestion=0.0, tol=1e-3, config=1),
     # configs[2]: knots mesh, ntime=63, congestion 0.1 (time pitch 64)
-    "knot63": dict(example="knot", kw={}, n_time=63, congestion=0.1, tol=1e-3),
+    "knot63": dict(example="knot", kw={}, n_time=63, congestion=0.1, tol=1e-3, config=2),
+    # configs[3]: ~100k-vertex torus, ntime=31
+    "torus100k": dict(example="torus", kw=dict(nu=400, nv=250), n_time=31, congestion=0.0, tol=1e-3, config=3),
     # configs[4] stand-in: 360 x 180 torus, V = 64 800, ntime=127 (time pitch 128), tol 1e-5
-    "torus65k_T127": dict(example="torus", kw=dict(nu=360, nv=180), n_time=127, congestion=0.0, tol=1e-5),
+    "torus65k_T127": dict(example="torus", kw=dict(nu=360, nv=180), n_time=127, congestion=0.0, tol=1e-5, config=4),
     # the survey's analytic case
-    "plane20": dict(example="plane", kw=dict(n=20), n_time=31, congestion=0.0, tol=1e-3),
+    "plane20": dict(example="plane", kw=dict(n=20), n_time=31, congestion=0.0, tol=1e-3, config=None),
 }
+ALL_CONFIGS = ["knot", "sphere10k", "knot63", "torus100k", "torus65k_T127"]
+STEADY = {"torus65k_T127": (40, 100), "torus100k": (100, 200)}     # (first timed iteration, timed iterations); default (100, 200)
 
 
 def parse():
@@ -46,7 +59,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="sphere10k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="knot", choices=sorted(WORKLOADS))
     ap.add_argument("--lap-solver", default="modal_direct", choices=["modal_direct", "modal_pcg", "spacetime_pcg"])
     ap.add_argument("--preconditioner", default="multigrid", choices=["multigrid", "jacobi"])
     ap.add_argument("--cg-tol", type=float, default=None)
@@ -54,17 +67,44 @@ def parse():
     ap.add_argument("--nd-leaf", type=int, default=None, help="leaf size of the nested dissection (default: solver default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-tol", action="store_true")
-    ap.add_argument("--no-reorder", action="store_true", help="keep the generator's vertex numbering (A/B of the RCM renumbering)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the table of the five BASELINE configurations")
+    ap.add_argument("--no-reorder", action="store_true", help="keep the generator's vertex numbering (A/B of the renumbering)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget of the cpu_baseline sample")
     return ap.parse_args()
+
+
+def git_commit():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def iteration_bytes(T, V, F, solve_bytes, z_mid_stored=False):
+    """Algorithmic bytes ONE iteration of the implemented algorithm moves, N = (T+1) V:
+        right-hand side        A, lambda_c, mu r (3TV); B, E r (6(T+1)F); b-hat w (N)
+        cone projection        beta_mid r (18TF); B r (3(T+1)F); A, beta_fst, beta_end r, z_fst, z_end, lambda w (6TV)
+        solve                  the factor twice + four vector passes (``solve_bytes``)
+        inverse transform      2N
+        steps 2+3, triangles   beta_mid r+w (36TF); B, E r+w (12(T+1)F); phi r (N); cone multiplier r (TV)
+        steps 2+3, vertices    11TV
+    z_mid (18TF) is written only on the iterations whose results are read back, never read."""
+    N = (T + 1) * V
+    words = (3 * T * V + 6 * (T + 1) * F + N) + (18 * T * F + 3 * (T + 1) * F + 6 * T * V) + 2 * N \
+        + (36 * T * F + 12 * (T + 1) * F + N + T * V) + 11 * T * V
+    if z_mid_stored:
+        words += 18 * T * F
+    return 8.0 * words + solve_bytes
 
 
 def cpu_baseline(geom, n_time, congestion, budget_s):
     """Time the CPU oracle (numpy + SuperLU restatement of the reference) on the same workload.
 
-    Bounded sample: operator setup is excluded (as for the GPU), then as many ALM iterations as
-    fit in ~budget_s seconds (at least 2)."""
+    Bounded sample: operator setup is excluded (as for the GPU), then as many ALM iterations as fit in ~budget_s / 2
+    seconds (at least 2), once on one thread and once the way the reference runs by default (is_multi_threads=True,
+    solver_socp.py:674-696: the Laplacian solve and the cone projection on two threads).  The faster one is `value`."""
     import importlib.util
+    import threading
 
     spec = importlib.util.spec_from_file_location("dots_oracle", os.path.join(ROOT, "oracle", "dots_oracle.py"))
     O = importlib.util.module_from_spec(spec)
@@ -78,24 +118,167 @@ def cpu_baseline(geom, n_time, congestion, budget_s):
         limit = threadpool_limits(limits=1)
     except Exception:  # pragma: no cover
         limit = contextlib.nullcontext()
+
+    def threaded_iterate(s):
+        a, b = threading.Thread(target=s.step_laplacian), threading.Thread(target=s.step_soc_projection)
+        a.start(); b.start(); a.join(); b.join()
+        s.step_q_lambda()
+        s.step_multipliers()
+
     with limit:
         t0 = time.perf_counter()
         s = O.OracleSolver(n_time, geom, congestion=congestion)
         s.scale_z(2.0)
         setup = time.perf_counter() - t0
         s.iterate()   # warm caches
-        n, t0 = 0, time.perf_counter()
-        while True:
-            s.iterate()
-            n += 1
-            el = time.perf_counter() - t0
-            if (el > budget_s and n >= 2) or n >= 400:
-                break
+        rates = {}
+        for tag, step in (("1 thread", s.iterate), ("2 threads", lambda: threaded_iterate(s))):
+            n, t0 = 0, time.perf_counter()
+            while True:
+                step()
+                n += 1
+                el = time.perf_counter() - t0
+                if (el > 0.5 * budget_s and n >= 2) or n >= 400:
+                    break
+            rates[tag] = (n / el, n)
+    best = max(rates, key=lambda k: rates[k][0])
     return {
-        "value": n / el, "unit": "ALM iterations/s", "cores": 1, "kind": "port",
-        "sample": f"{n} ALM iterations of the numpy/SuperLU oracle after setup ({setup:.1f} s setup excluded), "
+        "value": rates[best][0], "unit": "ALM iterations/s", "cores": 1 if best == "1 thread" else 2, "kind": "port",
+        "sample": f"numpy/SuperLU oracle after setup ({setup:.1f} s setup excluded): {rates['1 thread'][1]} iterations on 1 thread = "
+                  f"{rates['1 thread'][0]:.3f} it/s, {rates['2 threads'][1]} iterations with step 1 on 2 threads (the reference's default "
+                  f"is_multi_threads; it also runs numexpr on 4 threads, which numpy does not) = {rates['2 threads'][0]:.3f} it/s; "
                   f"1 BLAS thread, host {os.cpu_count()} logical CPUs",
     }
+
+
+class Timer:
+    def __init__(self, alm, dist):
+        self.alm, self.dist = alm, dist
+
+    def barrier(self):
+        import torch
+
+        self.alm.dev.sync()
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def run(self, n):
+        """n iterations between two barriers; seconds (max over ranks)."""
+        import torch
+
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            self.alm.iterate()
+        self.barrier()
+        el = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+
+def build_solver(args, wl, geom, nit, local_rank, world, tol=1e-30, time_limit=float("inf")):
+    from dots_socp_amd.socp.solver_socp import AlmSolver, DEFAULT_CG_TOL
+
+    cg_tol = args.cg_tol if args.cg_tol is not None else DEFAULT_CG_TOL
+    kw = {} if args.mg_coarsest is None else {"mg_coarsest": args.mg_coarsest}
+    if args.nd_leaf is not None:
+        kw["nd_leaf"] = args.nd_leaf
+    common = dict(congestion=wl["congestion"], nit=nit, tol=tol, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner,
+                  lap_solver=args.lap_solver, time_limit=time_limit, reorder=not args.no_reorder, **kw)
+    if world > 1:
+        from dots_socp_amd.distributed import ShardedAlmSolver, TorchComm
+
+        if args.lap_solver == "spacetime_pcg":
+            raise SystemExit("--gpus N>1 shards the time modes: use --lap-solver modal_direct or modal_pcg")
+        return ShardedAlmSolver(wl["n_time"], geom, comm=TorchComm(), **common)
+    return AlmSolver(wl["n_time"], geom, **common)
+
+
+def solve_roofline(alm, V, n_time):
+    """Roofline of the dominant kernel(s), hipEvent-timed on the context's own stream in the state the run left behind."""
+    if getattr(alm, "front_summary", None):
+        fs = alm.front_summary
+        ms_solve, bytes_solve = alm.dev.bench_kernel(which=3, reps=100)
+        achieved = bytes_solve / (ms_solve * 1e-3) / 1e9
+        launches = alm.dev.front_launches() if hasattr(alm.dev, "front_launches") else 2 * fs["levels"]
+        return {
+            "bound": "hbm", "kernel": "k_front_fwd + k_front_bwd (the two triangular sweeps of the multifrontal factor)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "ms_per_solve": ms_solve, "launches_per_solve": launches, "ms_per_launch": ms_solve / max(launches, 1),
+            "algorithmic_bytes_per_solve": bytes_solve, "factor": fs,
+        }, bytes_solve
+    ms_apply, bytes_apply = alm.dev.bench_kernel(which=0, reps=200)
+    ms_update, bytes_update = alm.dev.bench_kernel(which=1, reps=200)
+    achieved = bytes_apply / (ms_apply * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "k_cg_apply (fused direction update + K p + p.Kp partials)",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "ms_per_launch": ms_apply, "algorithmic_bytes_per_launch": bytes_apply,
+        "second_kernel": {"kernel": "k_cg_update", "ms_per_launch": ms_update,
+                          "achieved": bytes_update / (ms_update * 1e-3) / 1e9, "algorithmic_bytes_per_launch": bytes_update},
+        "working_set_note": "CG working set fits the 256 MiB Infinity Cache at this size" if V * (n_time + 1) * 8 * 6 < 256e6 else "",
+    }
+    if getattr(alm, "mg_summary", None):
+        ms_vc, bytes_vc = alm.dev.bench_kernel(which=2, reps=100)
+        roofline["multigrid_vcycle"] = {"ms_per_cycle": ms_vc, "finest_level_algorithmic_bytes": bytes_vc,
+                                        "achieved_finest_only": bytes_vc / (ms_vc * 1e-3) / 1e9, "hierarchy": alm.mg_summary}
+    return roofline, None
+
+
+def whole_iteration(T, V, F, solve_bytes, ms_per_step, label):
+    b = iteration_bytes(T, V, F, solve_bytes)
+    return {"algorithmic_bytes": b, "achieved": b / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s", "frac": b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "over": label, "note": "bytes the implemented iteration moves when z_mid is not materialised (bench.py: iteration_bytes); "
+                                   "KKT evaluations and penalty updates inside the window are not counted as bytes"}
+
+
+def time_to_tol(args, wl, geom, local_rank):
+    t1 = time.perf_counter()
+    solver = build_solver(args, wl, geom, 20000, local_rank, 1, tol=wl["tol"], time_limit=1000)
+    setup_s = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    while not solver.iterate():
+        pass
+    _, hist = solver.finalize(download=False)
+    solve_s = time.perf_counter() - t1
+    solver.close()
+    return {"tol": wl["tol"], "seconds": solve_s, "setup_seconds": setup_s, "iterations": int(hist.kkt_iteration[-1]) + 1,
+            "transport_cost": float(hist.history["Transportation cost"][-1]), "max_kkt": float(max(hist.kkt_errors[-1])),
+            "pcg_iterations": hist.solver_stats["cg_iterations"]}
+
+
+def config_entry(args, name, local_rank):
+    """One BASELINE configuration on one GPU: steady-state rate, sweeps' roofline, time to tol."""
+    from dots_socp_amd import meshes
+
+    wl = WORKLOADS[name]
+    geom, _ = meshes.example(wl["example"], **wl["kw"])
+    V, F, T = geom["vertices"].shape[0], geom["triangles"].shape[0], wl["n_time"]
+    first, count = STEADY.get(name, (100, 200))
+    alm = build_solver(args, wl, geom, first + count + 8, local_rank, 1)
+    tm = Timer(alm, None)
+    for _ in range(first):
+        alm.iterate()
+    el = tm.run(count)
+    ms = 1e3 * el / count
+    roof, solve_bytes = solve_roofline(alm, V, T)
+    entry = {
+        "workload": name, "baseline_config": wl["config"], "V": V, "F": F, "ntime": T, "congestion": wl["congestion"], "tol": wl["tol"],
+        "iterations_per_s": count / el, "ms_per_step": ms, "window": f"iterations {first}..{first + count - 1}",
+        "device_bytes": alm.dev.device_bytes(),
+        "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "ms_per_solve", "launches_per_solve",
+                                          "algorithmic_bytes_per_solve") if k in roof},
+    }
+    if solve_bytes is not None:
+        entry["roofline"]["whole_iteration"] = whole_iteration(T, V, F, solve_bytes, ms, entry["window"])
+    alm.close()
+    if not args.no_time_to_tol:
+        entry["time_to_tol"] = time_to_tol(args, wl, geom, local_rank)
+    return entry
 
 
 def main():
@@ -118,15 +301,10 @@ def main():
     torch.cuda.set_device(local_rank)
 
     from dots_socp_amd import meshes
-    from dots_socp_amd.socp.solver_socp import AlmSolver, DEFAULT_CG_TOL
 
     wl = WORKLOADS[args.workload]
     geom, _scale = meshes.example(wl["example"], **wl["kw"])
-    n_time, congestion, tol = wl["n_time"], wl["congestion"], wl["tol"]
-    cg_tol = args.cg_tol if args.cg_tol is not None else DEFAULT_CG_TOL
-    mg_kw = {} if args.mg_coarsest is None else {"mg_coarsest": args.mg_coarsest}
-    if args.nd_leaf is not None:
-        mg_kw["nd_leaf"] = args.nd_leaf
+    n_time, congestion = wl["n_time"], wl["congestion"]
     V, F = geom["vertices"].shape[0], geom["triangles"].shape[0]
 
     dist = None
@@ -138,86 +316,29 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-        from dots_socp_amd.distributed import ShardedAlmSolver, TorchComm
 
-        if args.lap_solver == "spacetime_pcg":
-            raise SystemExit("--gpus N>1 shards the time modes: use --lap-solver modal_direct or modal_pcg")
-        alm = ShardedAlmSolver(n_time, geom, comm=TorchComm(), congestion=congestion, nit=args.warmup + args.steps + 8,
-                               tol=1e-30, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner, lap_solver=args.lap_solver,
-                               time_limit=float("inf"), reorder=not args.no_reorder, **mg_kw)
-    else:
-        alm = AlmSolver(n_time, geom, congestion=congestion, nit=args.warmup + args.steps + 8, tol=1e-30,
-                        lap_solver=args.lap_solver, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner,
-                        time_limit=float("inf"), reorder=not args.no_reorder, **mg_kw)
-
-    def barrier():
-        alm.dev.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    steady_first, steady_count = STEADY.get(args.workload, (100, 200))
+    total = max(args.warmup + args.steps, steady_first) + steady_count + 8
+    alm = build_solver(args, wl, geom, total, local_rank, world)
+    tm = Timer(alm, dist)
 
     for _ in range(args.warmup):
         alm.iterate()
-    barrier()
     cg0 = alm.cg_total
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        alm.iterate()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = tm.run(args.steps)                                   # the driver's K steps after W warm-up steps
     cg_per_it = (alm.cg_total - cg0) / max(args.steps, 1)
     steps_time = dict(alm.run_history.steps_time)
+    done = args.warmup + args.steps
+    for _ in range(max(0, steady_first - done)):
+        alm.iterate()
+    steady_from = max(done, steady_first)
+    steady_el = tm.run(steady_count)
+    steady_ms = 1e3 * steady_el / steady_count
 
-    # ---- roofline of the dominant kernel(s), measured with hipEvents on the context's own stream in the
-    # state the timed region left behind
-    if getattr(alm, "front_summary", None):
-        fs = alm.front_summary
-        ms_solve, bytes_solve = alm.dev.bench_kernel(which=3, reps=100)
-        achieved = bytes_solve / (ms_solve * 1e-3) / 1e9
-        roofline = {
-            "bound": "hbm", "kernel": "k_front_fwd + k_front_bwd (the two triangular sweeps of the multifrontal factor: "
-                                      f"{2 * fs['levels']} launches per solve, one per tree height and sweep)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "ms_per_solve": ms_solve, "launches_per_solve": 2 * fs["levels"], "ms_per_launch": ms_solve / (2 * fs["levels"]),
-            "algorithmic_bytes_per_solve": bytes_solve, "factor": fs,
-        }
-    else:
-        ms_apply, bytes_apply = alm.dev.bench_kernel(which=0, reps=200)
-        ms_update, bytes_update = alm.dev.bench_kernel(which=1, reps=200)
-        achieved = bytes_apply / (ms_apply * 1e-3) / 1e9
-        roofline = {
-            "bound": "hbm", "kernel": "k_cg_apply (fused direction update + K p + p.Kp partials)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "ms_per_launch": ms_apply, "algorithmic_bytes_per_launch": bytes_apply,
-            "second_kernel": {"kernel": "k_cg_update", "ms_per_launch": ms_update,
-                              "achieved": bytes_update / (ms_update * 1e-3) / 1e9, "algorithmic_bytes_per_launch": bytes_update},
-            "working_set_note": "CG working set fits the 256 MiB Infinity Cache at this size" if V * (n_time + 1) * 8 * 6 < 256e6 else "",
-        }
-    if getattr(alm, "mg_summary", None):
-        ms_vc, bytes_vc = alm.dev.bench_kernel(which=2, reps=100)
-        roofline["multigrid_vcycle"] = {
-            "ms_per_cycle": ms_vc, "finest_level_algorithmic_bytes": bytes_vc,
-            "achieved_finest_only": bytes_vc / (ms_vc * 1e-3) / 1e9, "hierarchy": alm.mg_summary,
-        }
-    # SURVEY.md section 8(d)'s per-iteration figure: 2 S (every state array read and written once) + the right-hand
-    # side + the solve, over the measured step time
-    S_bytes = 8 * ((n_time + 1) * V + 7 * n_time * V + 6 * (n_time + 1) * F + 36 * n_time * F)
-    rhs_bytes = 8 * (3 * n_time * V + 6 * (n_time + 1) * F + 2 * (n_time + 1) * V)
-    if "algorithmic_bytes_per_solve" in roofline:
-        solve_bytes = roofline["algorithmic_bytes_per_solve"]
-    else:
+    roofline, solve_bytes = solve_roofline(alm, V, n_time)
+    if solve_bytes is None:
         solve_bytes = cg_per_it * (roofline["algorithmic_bytes_per_launch"] + roofline["second_kernel"]["algorithmic_bytes_per_launch"])
-    it_bytes = 2 * S_bytes + rhs_bytes + solve_bytes
-    roofline["whole_iteration"] = {
-        "algorithmic_bytes": it_bytes, "achieved": it_bytes / (elapsed / args.steps) / 1e9, "unit": "GB/s",
-        "frac": it_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
-        "note": "2*S + rhs + solve bytes over the measured step (SURVEY.md 8d); the driver moves less than 2*S on iterations that do not store z_mid",
-    }
+    roofline["whole_iteration"] = whole_iteration(n_time, V, F, solve_bytes, steady_ms, f"iterations {steady_from}..{steady_from + steady_count - 1}")
     # one streaming launch of known size: calibrates the FETCH_SIZE / WRITE_SIZE counters when this command runs
     # under rocprofv3 --pmc (profiles/tools/pmc_summary.py); a single launch, outside the timed region
     _, calib_bytes = alm.dev.bench_kernel(which=4, reps=1)
@@ -226,6 +347,8 @@ def main():
     if world == 1 and args.lap_solver == "modal_direct" and os.path.exists(traffic_file):
         with open(traffic_file) as fh:
             tr = json.load(fh)
+        # PMC counters cannot be read inside this process: the figure comes from the rocprofv3 --pmc passes of THIS command
+        # recorded by profiles/tools/collect_traffic.sh; traffic_source names the commit it was measured on
         roofline["traffic"] = tr["bytes_per_solve"]
         roofline["traffic_source"] = tr["source"]
     dev_bytes = alm.dev.device_bytes()
@@ -233,21 +356,22 @@ def main():
 
     extra = {}
     if rank == 0 and world == 1 and not args.no_time_to_tol:
-        t1 = time.perf_counter()
-        solver = AlmSolver(n_time, geom, congestion=congestion, nit=20000, tol=tol, lap_solver=args.lap_solver, cg_tol=cg_tol,
-                           device=local_rank, preconditioner=args.preconditioner, reorder=not args.no_reorder, **mg_kw)
-        setup_s = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        while not solver.iterate():
-            pass
-        _, hist = solver.finalize(download=False)
-        solve_s = time.perf_counter() - t1
-        solver.close()
-        extra["time_to_tol"] = {
-            "tol": tol, "seconds": solve_s, "setup_seconds": setup_s, "iterations": int(hist.kkt_iteration[-1]) + 1,
-            "transport_cost": float(hist.history["Transportation cost"][-1]),
-            "max_kkt": float(max(hist.kkt_errors[-1])), "pcg_iterations": hist.solver_stats["cg_iterations"],
-        }
+        extra["time_to_tol"] = time_to_tol(args, wl, geom, local_rank)
+    if rank == 0 and world == 1 and not args.no_configs and args.lap_solver == "modal_direct":
+        table = []
+        for name in ALL_CONFIGS:
+            if name == args.workload:
+                e = {"workload": name, "baseline_config": wl["config"], "V": V, "F": F, "ntime": n_time, "congestion": congestion, "tol": wl["tol"],
+                     "iterations_per_s": steady_count / steady_el, "ms_per_step": steady_ms,
+                     "window": f"iterations {steady_from}..{steady_from + steady_count - 1}", "device_bytes": dev_bytes,
+                     "roofline": {k: roofline[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "ms_per_solve",
+                                                           "launches_per_solve", "algorithmic_bytes_per_solve", "whole_iteration") if k in roofline}}
+                if "time_to_tol" in extra:
+                    e["time_to_tol"] = extra["time_to_tol"]
+                table.append(e)
+            else:
+                table.append(config_entry(args, name, local_rank))
+        extra["configs"] = table
 
     if rank != 0:
         if dist is not None:
@@ -259,12 +383,14 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {wl['example']} mesh V={V} F={F}, ntime={n_time}, congestion={congestion}, "
-                        f"lap_solver={args.lap_solver}{'' if world == 1 else ' (mode-sharded)'}"
-                        + ("" if args.lap_solver == "modal_direct" else f", cg_tol={cg_tol:g}, preconditioner={args.preconditioner}"),
+                        f"lap_solver={args.lap_solver}{'' if world == 1 else ' (sharded over ' + str(world) + ' ranks)'}"
+                        + ("" if args.lap_solver == "modal_direct" else f", preconditioner={args.preconditioner}"),
+            "baseline_config": wl["config"],
             "unknowns": V * (n_time + 1), "state_bytes": 8 * ((n_time + 1) * V + 7 * n_time * V + 6 * (n_time + 1) * F + 36 * n_time * F),
-            "device_bytes": dev_bytes, "pcg_iterations_per_step": cg_per_it,
-            "step_seconds": steps_time,
+            "device_bytes": dev_bytes, "pcg_iterations_per_step": cg_per_it, "step_seconds": steps_time, "commit": git_commit(),
         },
+        "steady_state": {"iterations_per_s": steady_count / steady_el, "ms_per_step": steady_ms,
+                         "window": f"iterations {steady_from}..{steady_from + steady_count - 1}"},
         "roofline": roofline,
     }
     line.update(extra)

@@ -10,7 +10,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libdotsocp_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ARRAY_IDS = {
     "phi": 0, "A": 1, "B": 2, "lambda_c": 3, "z_fst": 4, "z_mid": 5, "z_end": 6,
@@ -28,7 +28,8 @@ EXPORTS = [
     "dots_sync", "dots_upload", "dots_download", "dots_array_count", "dots_step", "dots_run_phase", "dots_kkt",
     "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
-    "dots_step_begin", "dots_step_end", "dots_shard_elems", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
+    "dots_slab_elems", "dots_slab_set_buffers", "dots_slab_stage", "dots_kkt_sums", "dots_kkt_combine", "dots_objective_sums",
+    "dots_objective_combine", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
     "dots_symbolic_build", "dots_symbolic_front_rows", "dots_symbolic_copy", "dots_symbolic_free",
 ]
 
@@ -49,7 +50,7 @@ class ProblemDesc(C.Structure):
         ("corner_ptr", _i32p), ("corner_idx", _i32p), ("lap_rowptr", _i32p), ("lap_col", _i32p), ("lap_val", _f64p),
         ("mu0", _f64p), ("mu1", _f64p), ("perm_vert", _i32p), ("perm_tri", _i32p),
         ("time_modes", _f64p), ("time_eigs", _f64p),
-        ("mode_begin", C.c_int32), ("mode_count", C.c_int32), ("mode_stride", C.c_int32), ("reserved", C.c_int32),
+        ("slab_begin", C.c_int32), ("slab_count", C.c_int32), ("slab_stride", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -104,6 +105,16 @@ class StepStats(C.Structure):
 _lib = None
 
 
+class SlabBuffers(C.Structure):
+    """dots_slab_buffers: device pointers of the exchange buffers of a time-slab context."""
+    NAMES = ("send_x", "send_nsq", "recv_x", "recv_nsq", "b_send", "b_recv", "x_send", "x_recv", "send_mu", "send_b", "recv_mu", "recv_b")
+    _fields_ = [(n, C.c_void_p) for n in NAMES]
+
+
+KKT_N_SUMS = 24
+SLAB_SIZES = {"vertex_halo": 0, "b_chunk": 1, "x_chunk": 2, "triangle_halo": 3}
+
+
 def library_path() -> str:
     return LIB_PATH
 
@@ -147,10 +158,14 @@ def load():
     lib.dots_norm_square.argtypes = [vp, C.c_int, C.c_int, _f64p]
     lib.dots_apply_operator.argtypes = [vp, C.c_int, C.c_double, _f64p, C.c_int64, _f64p, C.c_int64]
     lib.dots_bench_kernel.argtypes = [vp, C.c_int, C.c_int, _f64p, _f64p]
-    lib.dots_step_begin.argtypes = [vp, vp, C.c_int64, C.POINTER(StepStats)]
-    lib.dots_step_end.argtypes = [vp, vp, C.c_int64, C.POINTER(StepStats)]
-    lib.dots_shard_elems.argtypes = [vp]
-    lib.dots_shard_elems.restype = C.c_int64
+    lib.dots_slab_elems.argtypes = [vp, C.c_int]
+    lib.dots_slab_elems.restype = C.c_int64
+    lib.dots_slab_set_buffers.argtypes = [vp, C.POINTER(SlabBuffers)]
+    lib.dots_slab_stage.argtypes = [vp, C.c_int, C.POINTER(StepStats)]
+    lib.dots_kkt_sums.argtypes = [vp, C.c_uint32, _f64p]
+    lib.dots_kkt_combine.argtypes = [vp, C.c_uint32, _f64p, _f64p]
+    lib.dots_objective_sums.argtypes = [vp, _f64p]
+    lib.dots_objective_combine.argtypes = [vp, _f64p, _f64p]
     lib.dots_mg_setup.argtypes = [vp, C.POINTER(MgDesc)]
     lib.dots_mg_enable.argtypes = [vp, C.c_int]
     lib.dots_front_setup.argtypes = [vp, C.POINTER(FrontDesc)]
@@ -175,7 +190,7 @@ def load():
     lib.dots_device_bytes.restype = C.c_int64
     for n in EXPORTS:
         f = getattr(lib, n)
-        if n not in ("dots_last_error", "dots_array_count", "dots_device_bytes", "dots_shard_elems", "dots_tree_nodes", "dots_tree_free",
+        if n not in ("dots_last_error", "dots_array_count", "dots_device_bytes", "dots_slab_elems", "dots_tree_nodes", "dots_tree_free",
                      "dots_symbolic_front_rows", "dots_symbolic_free"):
             f.restype = C.c_int
     if lib.dots_abi_version() != ABI_VERSION:

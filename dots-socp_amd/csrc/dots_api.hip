@@ -33,11 +33,11 @@ int array_kind(int id) {
     }
 }
 int64_t array_count_host(const Dev &d, int id) {
-    switch (array_kind(id)) {
-        case 0: return (int64_t)(d.T + 1) * d.V;
-        case 1: return (int64_t)d.T * d.V;
-        case 2: return (int64_t)(d.T + 1) * d.F * 3;
-        default: return (int64_t)d.T * 18 * d.F;
+    switch (array_kind(id)) {      // a time slab exchanges its own time extent (corner arrays: one block per node)
+        case 0: return (int64_t)d.nl * d.V;
+        case 1: return (int64_t)d.ni * d.V;
+        case 2: return (int64_t)d.nl * d.F * 3;
+        default: return (int64_t)(d.slab ? d.nl : d.ni) * 18 * d.F;
     }
 }
 int64_t array_count_device(const Dev &d, int id) {
@@ -80,12 +80,32 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     d.T = p->n_time;
     d.V = p->n_vertices;
     d.F = p->n_triangles;
-    int tp = 8, sh = 3;
-    while (tp < d.T + 1) { tp <<= 1; ++sh; }
+    int tpg = 8, shg = 3;                     // global pitch: power of two >= T + 1
+    while (tpg < d.T + 1) { tpg <<= 1; ++shg; }
+    if (tpg > TILE_ELEMS) { set_error("n_time too large: T+1 must be <= 1024"); return DOTS_ERR_ARGUMENT; }
+    if (p->lap_solver == DOTS_LAP_MODAL_PCG && tpg > BLOCK) { set_error("modal solver needs T+1 <= 256"); return DOTS_ERR_ARGUMENT; }
+    const bool sharded = p->slab_count > 0 || p->slab_stride > 0;
+    d.t0 = 0; d.nl = d.T + 1; d.ni = d.T; d.slab = 0;
+    int tp = tpg, sh = shg;
+    if (sharded) {
+        if (p->lap_solver != DOTS_LAP_MODAL_PCG || p->slab_stride < 1 || p->slab_begin < 0 || p->slab_count < 0 ||
+            p->slab_begin + p->slab_count > d.T + 1 || p->slab_count > p->slab_stride ||
+            (p->slab_count > 0 && p->slab_begin % p->slab_stride != 0) ||
+            (p->slab_count < p->slab_stride && p->slab_count > 0 && p->slab_begin + p->slab_count != d.T + 1)) {
+            set_error("bad time slab (needs the modal solver, begin = rank * stride, 0 <= count <= stride, a short slab only at the end)");
+            return DOTS_ERR_ARGUMENT;
+        }
+        c->shard_begin = p->slab_begin;
+        c->shard_count = p->slab_count;
+        c->shard_stride = p->slab_stride;
+        c->shard_ranks = (d.T + 1 + p->slab_stride - 1) / p->slab_stride;
+        tp = 4; sh = 2;                       // local pitch: power of two >= the nodes per rank
+        while (tp < p->slab_stride) { tp <<= 1; ++sh; }
+        d.t0 = p->slab_begin; d.nl = p->slab_count; d.slab = 1;
+        d.ni = std::max(0, std::min(d.nl, d.T - d.t0));
+    }
     d.TP = tp;
     d.tp_shift = sh;
-    if (tp > TILE_ELEMS) { set_error("n_time too large: T+1 must be <= 1024"); return DOTS_ERR_ARGUMENT; }
-    if (p->lap_solver == DOTS_LAP_MODAL_PCG && tp > BLOCK) { set_error("modal solver needs T+1 <= 256"); return DOTS_ERR_ARGUMENT; }
     d.VT = d.FT = TILE_ELEMS / tp;
     d.n_vtiles = (d.V + d.VT - 1) / d.VT;
     d.n_ftiles = (3 * d.F + d.FT - 1) / d.FT;
@@ -145,18 +165,18 @@ static int build(Ctx *c, const dots_problem_desc *p) {
         UP(Q, p->time_modes, (d.T + 1) * (d.T + 1));
         {
             const int n = d.T + 1;
-            std::vector<double> qp((size_t)tp * tp, 0.0), qt((size_t)tp * tp, 0.0);
+            std::vector<double> qp((size_t)tpg * tpg, 0.0), qt((size_t)tpg * tpg, 0.0);
             for (int i = 0; i < n; ++i)
                 for (int j = 0; j < n; ++j) {
-                    qp[(size_t)i * tp + j] = p->time_modes[i * n + j];
-                    qt[(size_t)j * tp + i] = p->time_modes[i * n + j];
+                    qp[(size_t)i * tpg + j] = p->time_modes[i * n + j];
+                    qt[(size_t)j * tpg + i] = p->time_modes[i * n + j];
                 }
-            UP(Qpad, qp.data(), (int64_t)tp * tp);
-            UP(QpadT, qt.data(), (int64_t)tp * tp);
+            UP(Qpad, qp.data(), (int64_t)tpg * tpg);
+            UP(QpadT, qt.data(), (int64_t)tpg * tpg);
         }
-        std::vector<double> sig(tp, 0.0);
+        std::vector<double> sig(tpg, 0.0);
         for (int i = 0; i <= d.T; ++i) sig[i] = p->time_eigs[i];
-        UP(sigma, sig.data(), tp);
+        UP(sigma, sig.data(), tpg);
     }
 #undef UP
 
@@ -164,19 +184,13 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     for (int id = 0; id < DOTS_N_ARRAYS; ++id)
         if ((rc = dev_alloc(c, state[id], array_count_device(d, id)))) return rc;
     const int64_t nnode = (int64_t)V << sh;
-    const bool sharded = p->mode_count > 0 || p->mode_stride > 0;
-    if (sharded) {
-        if (p->lap_solver != DOTS_LAP_MODAL_PCG || p->mode_stride < 1 || p->mode_begin < 0 || p->mode_count < 0 ||
-            p->mode_begin + p->mode_count > d.T + 1 || p->mode_count > p->mode_stride) {
-            set_error("bad mode range (sharding needs the modal solver and 0 <= begin, count <= stride, begin+count <= T+1)");
-            return DOTS_ERR_ARGUMENT;
-        }
-        c->shard_begin = p->mode_begin;
-        c->shard_count = p->mode_count;
-        c->shard_stride = p->mode_stride;
-    }
-    if ((rc = dev_alloc(c, &d.cg_b, nnode))) return rc;
+    if (!sharded && (rc = dev_alloc(c, &d.cg_b, nnode))) return rc;      // a slab writes its right-hand side into slab.b_send
     if ((rc = dev_alloc(c, &d.lamc, nnode))) return rc;
+    if (sharded) {
+        double *hv = nullptr;
+        if ((rc = dev_alloc(c, &hv, V))) return rc;
+        d.phi_hi = hv;
+    }
     if (!sharded) {
         double **cgv[6] = {&d.cg_r, &d.cg_z, &d.cg_p0, &d.cg_p1, &d.cg_Ap, &d.cg_x};
         for (auto q : cgv)
@@ -192,22 +206,24 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     DOTS_HIP(hipHostMalloc((void **)&c->h_pinned, sizeof(double) * CgScalOffsets::TOTAL, hipHostMallocDefault));
     DOTS_HIP(hipHostMalloc((void **)&c->h_flags, sizeof(int) * FLAG_TOTAL, hipHostMallocDefault));
 
-    // the PCG's view of the device data (see Ctx::dcg)
+    // the PCG's view of the device data (see Ctx::dcg), and on a slab the global-time view of the transforms
     c->dcg = d;
+    c->dgt = d;
     if (sharded) {
-        Dev &g = c->dcg;
-        int tpl = 4, shl = 2;
-        while (tpl < p->mode_stride) { tpl <<= 1; ++shl; }
-        g.TP = tpl;
-        g.tp_shift = shl;
-        g.cg_ncol = p->mode_count;
-        std::vector<double> sig(tpl, 0.0);
-        for (int i = 0; i < p->mode_count; ++i) sig[i] = p->time_eigs[p->mode_begin + i];
-        if ((rc = dev_upload(c, &g.sigma, sig.data(), tpl))) return rc;
-        const int64_t nloc = (int64_t)V << shl;
-        double **cgv[6] = {&g.cg_r, &g.cg_z, &g.cg_p0, &g.cg_p1, &g.cg_Ap, &g.cg_x};
+        Dev &g = c->dcg;           // modes [shard_begin, shard_begin + shard_count): same partition, same pitch as the slab
+        g.cg_ncol = p->slab_count;
+        std::vector<double> sig(tp, 0.0);
+        for (int i = 0; i < p->slab_count; ++i) sig[i] = p->time_eigs[p->slab_begin + i];
+        if ((rc = dev_upload(c, &g.sigma, sig.data(), tp))) return rc;
+        double **cgv[5] = {&g.cg_r, &g.cg_z, &g.cg_p0, &g.cg_p1, &g.cg_Ap};     // cg_x = slab.x_send (dots_slab_set_buffers)
         for (auto q : cgv)
-            if ((rc = dev_alloc(c, q, nloc))) return rc;
+            if ((rc = dev_alloc(c, q, nnode))) return rc;
+        Dev &t = c->dgt;
+        t.TP = tpg; t.tp_shift = shg; t.t0 = 0; t.nl = d.T + 1; t.ni = d.T; t.slab = 0;
+        t.VT = t.FT = TILE_ELEMS / tpg;
+        t.n_vtiles = (d.V + t.VT - 1) / t.VT;
+        t.n_ftiles = (3 * d.F + t.FT - 1) / t.FT;
+        c->slab_b_chunk = nnode + V;
     }
 
     // KKT normalisation constants (solver_socp.py:303-313): means of the broadcast weight arrays
@@ -247,52 +263,43 @@ static int palm_step0(Ctx *c) {
     return launch_q_lambda_only(c);
 }
 
-static int run_iteration_begin(Ctx *c, dots_step_stats *st) {
-    int rc;
-    if ((rc = palm_step0(c))) return rc;
-    if (!st) {   // enqueue only; the cone projection rides in the right-hand-side launch (run_iteration_end then skips it)
-        c->soc_in_begin = c->soc_with_rhs;
-        if ((rc = launch_rhs(c, c->soc_in_begin != 0))) return rc;
-        return cg_solve(c, nullptr);
-    }
-    c->soc_in_begin = 0;
-    DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
-    if ((rc = launch_rhs(c))) return rc;
-    DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
-    if ((rc = cg_solve(c, st))) return rc;
-    DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
-    DOTS_HIP(hipEventSynchronize(c->ev[2]));
-    float t;
-    DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); st->ms_rhs += t;
-    DOTS_HIP(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); st->ms_laplacian += t;
-    DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[2])); st->ms_total += t;
-    return 0;
+// ---- time slabs: the stages of one iteration (include/dots_socp_hip.h, dots_slab_stage) ---------------------------
+__global__ __launch_bounds__(BLOCK) void k_slab_append_multiplier(Dev d, double *__restrict__ tail) {
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    // the cone multiplier of the interval that ends at the next slab's first node
+    if (v < d.V) tail[v] = (d.ni == d.nl && d.nl > 0) ? d.lamc[idxV(d, v, d.nl - 1)] : 0.0;
 }
 
-// second half (sharded contexts): phi from the gathered mode-space solutions, then steps 1-2, 2 and 3
-static int run_iteration_end(Ctx *c, const double *gathered, dots_step_stats *st) {
+static int slab_stage(Ctx *c, int stage) {
     int rc;
-    if (!st) {   // enqueue only
-        if ((rc = cg_finish_sharded(c, gathered))) return rc;
-        if (!c->soc_in_begin && (rc = launch_soc_projection(c, 1))) return rc;
-        c->soc_in_begin = 0;
-        c->zmid_stale = c->step_skip_zmid;
-        return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
+    const Dev &d = c->d;
+    switch (stage) {
+        case 0:       // [is_palm: step 0]; halos for the right-hand side and the projection
+            if (d.nl > 0 && (rc = palm_step0(c))) return rc;
+            return launch_slab_pack_iteration(c);
+        case 1:       // right-hand side of this slab's nodes + cone projection of its intervals -> b_send
+            if (d.nl > 0) {
+                if ((rc = launch_rhs(c, true))) return rc;
+                hipLaunchKernelGGL(k_slab_append_multiplier, dim3((d.V + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d,
+                                   c->slab.b_send + ((int64_t)d.V << d.tp_shift));
+                DOTS_HIP(hipGetLastError());
+            }
+            return 0;
+        case 2:       // forward transform of this rank's modes + solve -> x_send
+            return cg_solve(c, nullptr);
+        case 3:       // inverse transform for this slab, steps 2 and 3
+            if ((rc = cg_finish_sharded(c))) return rc;
+            c->zmid_stale = c->step_skip_zmid;
+            c->kkt_halo_fresh = 0;
+            if (d.nl == 0) return 0;
+            return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
+        case 4:       // halos of the KKT kernels
+            c->kkt_halo_fresh = 1;
+            return launch_slab_pack_kkt(c);
+        default:
+            set_error("slab_stage: unknown stage");
+            return DOTS_ERR_ARGUMENT;
     }
-    DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
-    if ((rc = cg_finish_sharded(c, gathered))) return rc;
-    if ((rc = launch_soc_projection(c, 1))) return rc;
-    DOTS_HIP(hipEventRecord(c->ev[3], c->stream));
-    if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
-    c->zmid_stale = c->step_skip_zmid;
-    DOTS_HIP(hipEventRecord(c->ev[4], c->stream));
-    DOTS_HIP(hipEventSynchronize(c->ev[4]));
-    float t;
-    DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[3])); st->ms_soc += t;
-    DOTS_HIP(hipEventElapsedTime(&t, c->ev[3], c->ev[4])); st->ms_q_lambda_multiplier += t;
-    DOTS_HIP(hipEventElapsedTime(&t, c->ev[2], c->ev[4])); st->ms_total += t;
-    st->alm_iterations += 1;
-    return 0;
 }
 
 static int run_iteration(Ctx *c, dots_step_stats *st) {
@@ -450,6 +457,7 @@ int dots_upload(dots_ctx *c, int id, const double *host, int64_t count) {
     if ((rc = launch_to_device_layout(c, id, c->stage))) return rc;
     DOTS_HIP(hipStreamSynchronize(c->stream));
     if (id == DOTS_Z_MID) c->zmid_stale = 0;
+    c->kkt_halo_fresh = 0;
     return 0;
 }
 int dots_download(dots_ctx *c, int id, double *host, int64_t count) {
@@ -463,39 +471,78 @@ int dots_download(dots_ctx *c, int id, double *host, int64_t count) {
     return 0;
 }
 
-int64_t dots_shard_elems(dots_ctx *c) {
+int64_t dots_slab_elems(dots_ctx *c, int which) {
     if (!c || c->shard_stride == 0) return -1;
-    return (int64_t)c->d.V << c->dcg.tp_shift;
+    const int64_t nnode = (int64_t)c->d.V << c->d.tp_shift;
+    switch (which) {
+        case DOTS_SLAB_VERTEX_HALO: return c->d.V;
+        case DOTS_SLAB_B_CHUNK: return nnode + c->d.V;
+        case DOTS_SLAB_X_CHUNK: return nnode;
+        case DOTS_SLAB_TRIANGLE_HALO: return (int64_t)3 * c->d.F;
+        default: return -1;
+    }
 }
 
-int dots_step_begin(dots_ctx *c, double *send, int64_t count, dots_step_stats *stats) {
+int dots_slab_set_buffers(dots_ctx *c, const dots_slab_buffers *b) {
     int rc = check(c);
     if (rc) return rc;
-    if (c->shard_stride == 0) { set_error("step_begin: context is not sharded"); return DOTS_ERR_STATE; }
-    if (!send || count != dots_shard_elems(c)) { set_error("step_begin: bad send buffer"); return DOTS_ERR_ARGUMENT; }
-    dots_step_stats local;
-    memset(&local, 0, sizeof local);
-    if ((rc = run_iteration_begin(c, stats ? &local : nullptr))) return rc;
-    if (c->dcg.cg_ncol > 0) DOTS_HIP(hipMemcpyAsync(send, c->dcg.cg_x, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, c->stream));
-    else DOTS_HIP(hipMemsetAsync(send, 0, sizeof(double) * (size_t)count, c->stream));
-    if (stats) {
-        DOTS_HIP(hipStreamSynchronize(c->stream));
-        *stats = local;
+    if (c->shard_stride == 0) { set_error("slab_set_buffers: context is not a time slab"); return DOTS_ERR_STATE; }
+    if (!b || !b->send_x || !b->send_nsq || !b->recv_x || !b->recv_nsq || !b->b_send || !b->b_recv || !b->x_send || !b->x_recv ||
+        !b->send_mu || !b->send_b || !b->recv_mu || !b->recv_b) {
+        set_error("slab_set_buffers: null buffer");
+        return DOTS_ERR_ARGUMENT;
     }
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    c->slab = *b;
+    Dev &d = c->d;
+    const int rank = c->shard_begin / c->shard_stride;
+    d.cg_b = b->b_send;                         // the right-hand side of this slab is written where the all-gather reads it
+    d.X_lo = b->recv_x;
+    d.nsq_hi = b->recv_nsq;
+    d.mu_lo = b->recv_mu;
+    d.B_hi = b->recv_b;
+    // the previous slab appended its last interval's cone multipliers to its chunk of the right-hand-side all-gather
+    d.lamc_lo = (rank > 0 && d.nl > 0) ? b->b_recv + (int64_t)(rank - 1) * c->slab_b_chunk + ((int64_t)d.V << d.tp_shift) : b->recv_x;
+    const Dev g0 = c->dcg, t0 = c->dgt;
+    c->dcg = d;                                 // the solver's view: same pitch, its own vectors, sigma slice, mode count
+    c->dcg.cg_ncol = g0.cg_ncol; c->dcg.sigma = g0.sigma;
+    c->dcg.cg_r = g0.cg_r; c->dcg.cg_z = g0.cg_z; c->dcg.cg_p0 = g0.cg_p0; c->dcg.cg_p1 = g0.cg_p1; c->dcg.cg_Ap = g0.cg_Ap;
+    c->dcg.cg_x = b->x_send;                    // ... the mode-space solution is written where the second all-gather reads it
+    c->dgt = d;                                 // the transforms' view: same pointers, global-time geometry
+    c->dgt.TP = t0.TP; c->dgt.tp_shift = t0.tp_shift; c->dgt.t0 = 0; c->dgt.nl = d.T + 1; c->dgt.ni = d.T; c->dgt.slab = 0;
+    c->dgt.VT = t0.VT; c->dgt.FT = t0.FT; c->dgt.n_vtiles = t0.n_vtiles; c->dgt.n_ftiles = t0.n_ftiles;
+    // the PCG's warm start (its own previous solution) and the buffers' padding start from zero
+    DOTS_HIP(hipMemsetAsync(b->x_send, 0, sizeof(double) * ((size_t)d.V << d.tp_shift), c->stream));
+    DOTS_HIP(hipMemsetAsync(b->b_send, 0, sizeof(double) * (size_t)c->slab_b_chunk, c->stream));
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    c->slab_stage = 0;
     return 0;
 }
 
-int dots_step_end(dots_ctx *c, const double *recv, int64_t count, dots_step_stats *stats) {
+int dots_slab_stage(dots_ctx *c, int stage, dots_step_stats *stats) {
     int rc = check(c);
     if (rc) return rc;
-    if (c->shard_stride == 0) { set_error("step_end: context is not sharded"); return DOTS_ERR_STATE; }
-    const int n_ranks = (c->d.T + 1 + c->shard_stride - 1) / c->shard_stride;
-    const int64_t elems = dots_shard_elems(c);
-    if (!recv || count < n_ranks * elems || count % elems != 0) { set_error("step_end: bad receive buffer (need >= n_ranks chunks of shard_elems doubles)"); return DOTS_ERR_ARGUMENT; }
-    dots_step_stats local;
-    memset(&local, 0, sizeof local);
-    if ((rc = run_iteration_end(c, recv, stats ? &local : nullptr))) return rc;
-    if (stats) *stats = local;
+    if (c->shard_stride == 0) { set_error("slab_stage: context is not a time slab"); return DOTS_ERR_STATE; }
+    if (!c->slab.b_send) { set_error("slab_stage: no exchange buffers (dots_slab_set_buffers)"); return DOTS_ERR_STATE; }
+    if (stage < 0 || stage > 4) { set_error("slab_stage: unknown stage"); return DOTS_ERR_ARGUMENT; }
+    if (stage <= 3 && stage != c->slab_stage) { set_error("slab_stage: stages must be called in the order 0, 1, 2, 3"); return DOTS_ERR_STATE; }
+    if (stage == 4 && c->slab_stage != 0) { set_error("slab_stage: the KKT halos are packed between iterations"); return DOTS_ERR_STATE; }
+    if (!stats) {
+        if ((rc = slab_stage(c, stage))) return rc;
+    } else {
+        DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
+        if ((rc = slab_stage(c, stage))) return rc;
+        DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
+        DOTS_HIP(hipEventSynchronize(c->ev[1]));
+        float t;
+        DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
+        memset(stats, 0, sizeof *stats);
+        stats->ms_total = t;
+        if (stage == 1) stats->ms_rhs = stats->ms_soc = 0.5 * t;      // one launch: right-hand side and projection together
+        if (stage == 2) { stats->ms_laplacian = t; stats->cg_iterations = stats->cg_last_iterations = c->last_cg_iters; }
+        if (stage == 3) { stats->ms_q_lambda_multiplier = t; stats->alm_iterations = 1; }
+    }
+    if (stage <= 3) c->slab_stage = (stage + 1) & 3;
     return 0;
 }
 
@@ -517,7 +564,7 @@ int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
     int rc = check(c);
     if (rc) return rc;
     if (n_iters < 0) { set_error("n_iters < 0"); return DOTS_ERR_ARGUMENT; }
-    if (c->shard_stride != 0) { set_error("dots_step on a sharded context: use dots_step_begin / dots_step_end"); return DOTS_ERR_STATE; }
+    if (c->shard_stride != 0) { set_error("dots_step on a time slab: use dots_slab_stage"); return DOTS_ERR_STATE; }
     dots_step_stats local;
     memset(&local, 0, sizeof local);
     for (int i = 0; i < n_iters; ++i)
@@ -539,6 +586,7 @@ int dots_step_flags(dots_ctx *c, uint32_t flags) {
 int dots_run_phase(dots_ctx *c, int phase, dots_step_stats *stats) {
     int rc = check(c);
     if (rc) return rc;
+    if (c->shard_stride != 0) { set_error("run_phase works on whole arrays: not available on a time slab"); return DOTS_ERR_STATE; }
     dots_step_stats local;
     memset(&local, 0, sizeof local);
     switch (phase) {
@@ -566,12 +614,47 @@ int dots_kkt(dots_ctx *c, uint32_t mask, double *out) {
     if (!out || (mask >> DOTS_N_KKT)) { set_error("kkt: bad mask or null output"); return DOTS_ERR_ARGUMENT; }
     if (!mask) return 0;
     if (c->zmid_stale && (mask & (1u << DOTS_KKT_PRIM_Z))) { set_error("kkt: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
+    if (c->shard_stride != 0) { set_error("kkt on a time slab: use dots_kkt_sums / dots_kkt_combine around the caller's all-reduce"); return DOTS_ERR_STATE; }
     return kkt_evaluate(c, mask, out);
 }
+int dots_kkt_sums(dots_ctx *c, uint32_t mask, double *sums) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (!sums || (mask >> DOTS_N_KKT)) { set_error("kkt_sums: bad mask or null output"); return DOTS_ERR_ARGUMENT; }
+    static_assert(DOTS_KKT_N_SUMS == MAX_SUMS, "header and kernels disagree on the number of KKT sums");
+    for (int i = 0; i < DOTS_KKT_N_SUMS; ++i) sums[i] = 0.0;
+    if (!mask) return 0;
+    if (c->zmid_stale && (mask & (1u << DOTS_KKT_PRIM_Z))) { set_error("kkt: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
+    if (c->shard_stride != 0 && !c->kkt_halo_fresh && (mask & ((1u << DOTS_KKT_DUAL_ALPHA) | (1u << DOTS_KKT_COMP_RHO_FQ) | (1u << DOTS_KKT_COMP_M_RHO_B)))) {
+        set_error("kkt_sums: the KKT halos are stale (dots_slab_stage 4 + exchange first)");
+        return DOTS_ERR_STATE;
+    }
+    return kkt_sums(c, mask, sums);
+}
+int dots_kkt_combine(dots_ctx *c, uint32_t mask, const double *sums, double *out) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (!sums || !out || (mask >> DOTS_N_KKT)) { set_error("kkt_combine: bad argument"); return DOTS_ERR_ARGUMENT; }
+    return kkt_combine(c, mask, sums, out);
+}
+int dots_objective_sums(dots_ctx *c, double *sums) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (!sums) { set_error("null output"); return DOTS_ERR_ARGUMENT; }
+    return objective_sums(c, sums);
+}
+int dots_objective_combine(dots_ctx *c, const double *sums, double *out) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (!sums || !out) { set_error("null argument"); return DOTS_ERR_ARGUMENT; }
+    return objective_combine(c, sums, out);
+}
+
 int dots_objective(dots_ctx *c, double *out) {
     int rc = check(c);
     if (rc) return rc;
     if (!out) { set_error("null output"); return DOTS_ERR_ARGUMENT; }
+    if (c->shard_stride != 0) { set_error("objective on a time slab: use dots_objective_sums / dots_objective_combine"); return DOTS_ERR_STATE; }
     return objective_evaluate(c, out);
 }
 
@@ -579,17 +662,20 @@ int dots_adjust_penalty(dots_ctx *c, double factor) {
     int rc = check(c);
     if (rc) return rc;
     if (!(factor > 0)) { set_error("factor must be positive"); return DOTS_ERR_ARGUMENT; }
+    c->kkt_halo_fresh = 0;
     return launch_adjust_penalty(c, factor);
 }
 int dots_scale_z(dots_ctx *c, double z_mul, double beta_mul, double sz_new) {
     int rc = check(c);
     if (rc) return rc;
+    c->kkt_halo_fresh = 0;
     return launch_scale_z(c, z_mul, beta_mul, sz_new);
 }
 int dots_scale_arrays(dots_ctx *c, uint32_t mask, double factor) {
     int rc = check(c);
     if (rc) return rc;
     if (mask >> DOTS_N_ARRAYS) { set_error("bad array mask"); return DOTS_ERR_ARGUMENT; }
+    c->kkt_halo_fresh = 0;
     for (int id = 0; id < DOTS_N_ARRAYS; ++id)
         if ((mask >> id) & 1u)
             if ((rc = launch_scale_array(c, id, factor))) return rc;

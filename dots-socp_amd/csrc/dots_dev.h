@@ -7,6 +7,14 @@
 //     triangle arrays          B[f][c][t]              idxF(f,c,t)     = (f*3+c)*TP + t
 //     corner arrays            z_mid[f][k][s][c][t]    idxM(f,k,s,c,t) = ((((f*3+k)*2+s)*3+c)*TP + t
 // Interval arrays use t in [0,T), node arrays t in [0,T]; padding columns stay zero.
+// Corner entries live in the column of the NODE they are compared with (z_mid[t][s] pairs with B[t + s],
+// solver_socp.py:934-940): column t + s.  The thread that owns B[f][c][node] then owns every corner entry of
+// its column, which is what lets the time axis be cut into slabs without any exchange inside steps 2+3.
+//
+// Time slabs (multi-GPU, one context per rank): a context holds the columns of the nodes [t0, t0 + nl) only
+// (local column j = node t0 + j = interval t0 + j); T stays the GLOBAL number of intervals.  What a kernel needs
+// from the neighbouring slabs arrives in small per-vertex / per-triangle halo arrays (X_lo ... B_hi below).
+// On one GPU t0 = 0, nl = T + 1, ni = T and no halo is ever read.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -36,6 +44,10 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 // Everything a kernel needs, passed by value.
 struct Dev {
     int T, V, F, TP, tp_shift;
+    int t0;          // global index of the node in local column 0
+    int nl;          // nodes held here (columns [0, nl));  T + 1 on one GPU
+    int ni;          // intervals held here = min(nl, T - t0);  T on one GPU
+    int slab;        // 1: this context is one time slab of a multi-GPU solve
     int VT;          // vertices per tile = TILE_ELEMS / TP
     int n_vtiles;    // ceil(V / VT)
     int FT;          // (triangle,component) rows per tile = TILE_ELEMS / TP
@@ -64,6 +76,13 @@ struct Dev {
     // state
     double *phi, *A, *B, *lam, *zf, *zm, *ze, *mu, *E, *bf, *bm, *be;
     double *lamc;            // [V][TP] cone multiplier of the last projection (z_mid = lamc/D * pre-image, rebuilt in steps 2+3)
+    // halos of a time slab (device arrays, written by dots_slab_unpack / the inverse transform; see SlabHalo in dots_api.hip)
+    const double *X_lo;      // [V]  (A + lambda_c - mu) of interval t0 - 1           (right-hand side at node t0)
+    const double *lamc_lo;   // [V]  cone multiplier of interval t0 - 1                (steps 2+3 at node t0)
+    const double *mu_lo;     // [V]  mu of interval t0 - 1                             (KKT: Dual(alpha), Comp(m, rho o B))
+    const double *nsq_hi;    // [V]  s = 1 half of the cone's squared norm for interval t0 + nl - 1, formed by the next slab
+    double *phi_hi;          // [V]  phi at node t0 + nl (written by this rank's inverse transform)
+    const double *B_hi;      // [3F] B at node t0 + nl                                  (KKT: Comp(rho, f(q)))
     // PCG workspace (node layout)
     double *cg_b, *cg_r, *cg_z, *cg_p0, *cg_p1, *cg_Ap, *cg_x;
     double *partials;        // [MAX_SUMS or NC][n partial blocks]
@@ -159,7 +178,9 @@ int launch_operator(Ctx *c, int op, double scale, const double *in_staged, doubl
 int launch_calibration(Ctx *c, double *bytes_each_way);
 int cg_solve(Ctx *c, dots_step_stats *stats, bool defer_inverse = false);   // defer_inverse: phi is produced by the caller (soc_takes_inverse)
 int cg_apply_operator(Ctx *c, const double *x_node, double *y_node);  // y = K x in node layout
-int cg_finish_sharded(Ctx *c, const double *gathered);                // phi from all ranks' mode-space solutions
+int cg_finish_sharded(Ctx *c);                                        // phi of this time slab from all ranks' mode-space solutions (slab.x_recv)
+int launch_slab_pack_iteration(Ctx *c);     // halos the neighbours need before the right-hand side / the projection -> slab.send_x, slab.send_nsq
+int launch_slab_pack_kkt(Ctx *c);           // halos the neighbours' KKT kernels need -> slab.send_mu, slab.send_b
 int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes);
 int64_t cg_partials_needed(const Dev &d);   // doubles of Dev::partials the PCG uses
 int front_setup(Ctx *c, const dots_front_desc *desc);
@@ -168,7 +189,12 @@ int front_factorize(Ctx *c, const dots_front_desc *desc, FrontDev &f, const std:
 int front_solve(Ctx *c, const double *bhat, double *y, double *x);   // x = A^-1 bhat for every mode of the PCG view (y: scratch)
 int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int nb, int ept, int vt, int G);  // enqueue z = MG(r); z holds D^-1 r on entry
 int kkt_evaluate(Ctx *c, uint32_t mask, double *out);
+int kkt_sums(Ctx *c, uint32_t mask, double *sums);                          // the weighted sums of this context's time slab
+int kkt_combine(Ctx *c, uint32_t mask, const double *sums, double *out);    // the residuals from the sums of the whole problem
+int kkt_n_sums();
 int objective_evaluate(Ctx *c, double *out);
+int objective_sums(Ctx *c, double *sums);
+int objective_combine(Ctx *c, const double *sums, double *out);
 int norm_square(Ctx *c, int array_id, int part, double *out);
 int reduce_partials(Ctx *c, const double *partials, int n_slots, int n_blocks, int first_slot);  // -> scal[SUMS+first_slot+slot]
 
@@ -177,9 +203,17 @@ struct Ctx {
     // The PCG's view of the device data.  Identical to `d` on one GPU.  When the time modes are sharded
     // over ranks it has this rank's column count, its own (smaller) pitch, PCG vectors and sigma slice.
     Dev dcg{};
-    int shard_begin = 0;    // first time mode of this context
-    int shard_count = 0;    // modes of this context; 0 = not sharded (all T+1)
-    int shard_stride = 0;   // modes per rank (same on every rank) = layout of the gathered buffer
+    // Multi-GPU: this context is one TIME SLAB of the problem.  Rank r holds the nodes [r * stride, r * stride + count) of
+    // every state array (d: local pitch, t0, nl, ni) AND solves the time modes with the same indices (dcg).
+    int shard_begin = 0;    // first node = first time mode of this context
+    int shard_count = 0;    // nodes = modes of this context (may be 0 on trailing ranks)
+    int shard_stride = 0;   // nodes per rank (same on every rank) = layout of the gathered buffers; 0 = not sharded
+    int shard_ranks = 0;    // ranks with at least one node
+    Dev dgt{};              // global-time view for the transforms of a slab context: pitch >= T + 1, Q
+    dots_slab_buffers slab{};     // exchange buffers (caller's device memory, dots_slab_set_buffers)
+    int64_t slab_b_chunk = 0;     // doubles one rank contributes to the right-hand-side all-gather: V * pitch + V
+    int slab_stage = 0;           // next stage dots_slab_stage expects
+    int kkt_halo_fresh = 0;       // mu_lo / B_hi belong to the current iterate
     dots_params prm{};
     int device = 0;
     int lap_solver = 0;
@@ -199,7 +233,6 @@ struct Ctx {
     int mg_tail_rows = 256;       // levels with at most this many rows run inside the single tail launch (DOTS_MG_TAIL_ROWS)
     int cg_graph_mg = -1;
     int soc_with_rhs = 1;         // DOTS_SOC_WITH_RHS=0: keep the projection after the solve (A/B measurements)
-    int soc_in_begin = 0;         // the projection of the current sharded iteration already ran in dots_step_begin
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
     int step_palm = 0;            // dots_step_flags: every iteration opens with the (q, lambda_c) closed form (is_palm = True)
     int zmid_stale = 0;           // z_mid does not belong to the current iterate
@@ -256,8 +289,17 @@ int array_kind(int array_id);  // 0 node (T+1,V), 1 interval (T,V), 2 triangle (
 // ---- device helpers ---------------------------------------------------------------------
 __device__ __forceinline__ int idxV(const Dev &d, int v, int t) { return (v << d.tp_shift) + t; }
 __device__ __forceinline__ int64_t idxF(const Dev &d, int f, int c, int t) { return ((int64_t)(f * 3 + c) << d.tp_shift) + t; }
+// t: LOCAL interval index (interval - t0), -1 <= t; the entry sits in the column of its node t + s
 __device__ __forceinline__ int64_t idxM(const Dev &d, int fk, int s, int c, int t) {
-    return ((int64_t)((fk * 2 + s) * 3 + c) << d.tp_shift) + t;
+    return ((int64_t)((fk * 2 + s) * 3 + c) << d.tp_shift) + t + s;
+}
+// slab predicates for local column t
+__device__ __forceinline__ bool first_node(const Dev &d, int t) { return d.t0 + t == 0; }       // global node 0
+__device__ __forceinline__ bool last_node(const Dev &d, int t) { return d.t0 + t == d.T; }      // global node T
+__device__ __forceinline__ bool has_prev_interval(const Dev &d, int t) { return d.t0 + t > 0; } // interval t - 1 exists
+// node t + 1 of a node array x (halo when it belongs to the next slab)
+__device__ __forceinline__ double next_node(const Dev &d, const double *x, const double *hi, int64_t row, int t) {
+    return (t + 1 < d.nl) ? x[(row << d.tp_shift) + t + 1] : hi[row];
 }
 
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give every XCD one

@@ -3,6 +3,8 @@
 // All HBM-bound fp64; one thread per (row, time) element, rows = vertices or (triangle, xyz).
 #include "dots_dev.h"
 
+#include <algorithm>
+
 namespace dots {
 
 // ------------------------------------------------------------------------------------------
@@ -18,24 +20,50 @@ namespace dots {
 // multiplier lambda[v][t] (T*V values instead of 18*T*F) and steps 2+3 rebuild z_mid = lambda/D * pre-image on
 // the fly from beta_mid and B, which they read anyway: the second corner walk and 18*T*F stores disappear here,
 // 18*T*F loads disappear there.
+// The squared norm is accumulated in two halves, s = 0 (entries of node t) and s = 1 (entries of node t + 1), each over
+// the corner list in order: when node t + 1 belongs to the next time slab that rank forms the s = 1 half from its own
+// B and beta_mid (soc_half_of_first_node) and this one reads it from the halo -- bit for bit the same sum.
+__device__ __forceinline__ double soc_half(const Dev &d, int v, int t, int s, double sB) {
+    double acc = 0.0;
+    for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+        const int fk = d.cidx[j];
+        const int f = fk / 3;
+        const double D = d.c_D[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double w = D * (sB * d.B[idxF(d, f, c, t + s)] - d.bm[idxM(d, fk, s, c, t)]);
+            acc += w * w;
+        }
+    }
+    return acc;
+}
+
 template <bool ONLY_MULTIPLIER>
 __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double sz, double cd) {
     const double sB = sz * INV_SQRT3;
     const int iv = idxV(d, v, t);
     const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
-    double acc = 0.0;
+    const bool own1 = t + 1 < d.nl;      // node t + 1 is held here (always on one GPU)
+    double acc0 = 0.0, acc1 = 0.0;
     for (int j = j0; j < j1; ++j) {
         const int fk = d.cidx[j];
         const int f = fk / 3;
         const double D = d.c_D[j];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int c = 0; c < 3; ++c) {
+            const double w = D * (sB * d.B[idxF(d, f, c, t)] - d.bm[idxM(d, fk, 0, c, t)]);
+            acc0 += w * w;
+        }
+        if (own1) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const double w = D * (sB * d.B[idxF(d, f, c, t + s)] - d.bm[idxM(d, fk, s, c, t)]);
-                acc += w * w;
+                const double w = D * (sB * d.B[idxF(d, f, c, t + 1)] - d.bm[idxM(d, fk, 1, c, t)]);
+                acc1 += w * w;
             }
+        }
     }
+    if (!own1) acc1 = d.nsq_hi[v];
+    const double acc = acc0 + acc1;
     const double a = d.A[iv];
     const double w_fst = cd - sz * a - d.bf[iv];
     const double w_end = cd + sz * a - d.be[iv];
@@ -48,7 +76,7 @@ __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double s
         d.lamc[iv] = lam;
         return;
     }
-    for (int j = j0; j < j1; ++j) {
+    for (int j = j0; j < j1; ++j) {      // (not reached on a time slab: the full projection needs every node of the interval here)
         const int fk = d.cidx[j];
         const int f = fk / 3;
         const double D = d.c_D[j];
@@ -89,9 +117,45 @@ __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, doub
     const int v0 = tile * d.VT;
     for (int e = (blockIdx.x / G8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
         const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (v >= d.V || t >= d.T) continue;
+        if (v >= d.V || t >= d.ni) continue;
         soc_element<ONLY_MULTIPLIER>(d, v, t, sz, cd);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Time slabs: what the neighbouring slabs need from this one (dots_slab_stage 0 and 4).
+//   forward  (to the next slab, which starts at node t0 + nl):   X = A + lambda_c - mu (right-hand side at its first node) or
+//            mu (KKT) of this slab's last interval nl - 1
+//   backward (to the previous slab, which ends with interval t0 - 1): the s = 1 half of that interval's cone norms --
+//            its entries are compared with B of THIS slab's first node and live in this slab's column 0 -- or B of the
+//            first node (KKT: Comp(rho, f(q)))
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_slab_pack_iteration(Dev d, double sz, double *__restrict__ send_x, double *__restrict__ send_nsq) {
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= d.V) return;
+    if (d.t0 + d.nl <= d.T) {        // a next slab exists: interval nl - 1 is this slab's last and ends at its first node
+        const int iv = idxV(d, v, d.nl - 1);
+        send_x[v] = d.A[iv] + d.lam[iv] - d.mu[iv];
+    }
+    if (d.t0 > 0) send_nsq[v] = soc_half(d, v, -1, 1, sz * INV_SQRT3);
+}
+__global__ __launch_bounds__(BLOCK) void k_slab_pack_kkt(Dev d, double *__restrict__ send_mu, double *__restrict__ send_b) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < d.V && d.t0 + d.nl <= d.T) send_mu[i] = d.mu[idxV(d, i, d.nl - 1)];
+    if (i < 3 * d.F && d.t0 > 0) send_b[i] = d.B[(int64_t)i << d.tp_shift];
+}
+int launch_slab_pack_iteration(Ctx *c) {
+    if (c->d.nl == 0) return 0;
+    hipLaunchKernelGGL(k_slab_pack_iteration, dim3((c->d.V + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->d, c->prm.scale_z, c->slab.send_x, c->slab.send_nsq);
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+int launch_slab_pack_kkt(Ctx *c) {
+    if (c->d.nl == 0) return 0;
+    const int n = std::max(c->d.V, 3 * c->d.F);
+    hipLaunchKernelGGL(k_slab_pack_kkt, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->d, c->slab.send_mu, c->slab.send_b);
+    DOTS_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_soc_projection(Ctx *c, int zmid_mode, bool with_inverse) {
@@ -119,8 +183,9 @@ __device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r
     const double m = d.mass_v[v];
     const double ih = 1.0 / d.h;
     double xt = 0.0, xm = 0.0;
-    if (t < d.T) xt = (d.A[iv] + d.lam[iv] - d.mu[iv]) * m;
+    if (t < d.ni) xt = (d.A[iv] + d.lam[iv] - d.mu[iv]) * m;
     if (t > 0) xm = (d.A[iv - 1] + d.lam[iv - 1] - d.mu[iv - 1]) * m;
+    else if (has_prev_interval(d, t)) xm = d.X_lo[v] * m;      // interval t0 - 1 lives in the previous time slab
     double rhs = (xt - xm) * ih;
     double ds = 0.0;
     for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
@@ -132,8 +197,8 @@ __device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r
         }
     }
     rhs -= ds;
-    if (t == 0) rhs += d.mu0[v] / (r * d.h);
-    if (t == d.T) rhs -= d.mu1[v] / (r * d.h);
+    if (first_node(d, t)) rhs += d.mu0[v] / (r * d.h);
+    if (last_node(d, t)) rhs -= d.mu1[v] / (r * d.h);
     rhs -= eps * m * d.phi[iv];
     return -rhs;
 }
@@ -146,7 +211,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps, int 
         const int st = xcd_tile(b % G8, d.n_vtiles);
         if (st >= d.n_vtiles) return;
         const int e = (b / G8) * BLOCK + threadIdx.x, v = st * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (v < d.V && t < d.T) soc_element<true>(d, v, t, sz, cd);
+        if (v < d.V && t < d.ni) soc_element<true>(d, v, t, sz, cd);
         return;
     }
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
@@ -155,7 +220,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps, int 
         const int v0 = tile * d.VT;
         for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
             const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
-            if (v >= d.V || t > d.T) continue;
+            if (v >= d.V || t >= d.nl) continue;
             const double b = rhs_value(d, v, t, r, eps);
             d.cg_b[idxV(d, v, t)] = b;
             part[0] += b;
@@ -176,7 +241,7 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double ep
         const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
         if (st >= d.n_vtiles) return;
         const int e = threadIdx.x, v = st * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (v < d.V && t < d.T) soc_element<true>(d, v, t, sz, cd);
+        if (v < d.V && t < d.ni) soc_element<true>(d, v, t, sz, cd);
         return;
     }
     extern __shared__ double tm_lds[];
@@ -199,7 +264,7 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, doub
         const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
         if (st >= d.n_vtiles) return;
         const int e = threadIdx.x, v = st * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (v < d.V && t < d.T) soc_element<true>(d, v, t, sz, cd);
+        if (v < d.V && t < d.ni) soc_element<true>(d, v, t, sz, cd);
         return;
     }
     extern __shared__ double xs_m[];                    // [TM_ROWS][TP + 1]
@@ -254,9 +319,9 @@ __device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, dou
     const double ia2 = 1.0 / a2, a12 = a1 / a2, cl = cr / (1.0 + cr), ih = 1.0 / d.h;
     for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
         const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (v >= d.V || t >= d.T) continue;
+        if (v >= d.V || t >= d.ni) continue;
         const int iv = idxV(d, v, t);
-        const double dphi = (d.phi[iv + 1] - d.phi[iv]) * ih;
+        const double dphi = (next_node(d, d.phi, d.phi_hi, v, t) - d.phi[iv]) * ih;
         const double mu = d.mu[iv], zf = d.zf[iv], ze = d.ze[iv], bf = d.bf[iv], be = d.be[iv];
         const double memo = dphi + mu;
         const double a = ia2 * memo + a12 * (ze + be - zf - bf);
@@ -289,12 +354,13 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
     const double diag_in = 1.0 + 2.0 * sz * sz, diag_bd = 1.0 + sz * sz;
     for (int e = (blockIdx.x / nf8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
         const int row = row0 + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (row >= 3 * d.F || t > d.T) continue;
+        if (row >= 3 * d.F || t >= d.nl) continue;
         const int f = row / 3, c = row - 3 * f;
-        // All loads first and unconditional (intervals past the ends are clamped to a valid one and masked
-        // afterwards): the compiler then issues them back to back instead of one wait per guarded load.
-        const bool has0 = t < d.T, has1 = t > 0;
-        const int t0 = has0 ? t : t - 1, t1 = has1 ? t - 1 : t;      // T >= 1: both are valid interval indices
+        // All loads first and unconditional: the compiler then issues them back to back instead of one wait per guarded
+        // load.  Both corner entries of this node sit in ITS column (idxM), whether their interval exists or not (then the
+        // slot holds a zero that is masked below); the multiplier of interval t - 1 comes from the previous time slab's
+        // halo when this is the slab's first node.
+        const bool has0 = t < d.ni, has1 = has_prev_interval(d, t);
         const int64_t ie = idxF(d, f, c, t);
         int vk[3];
         double hk[3], Dk[3], phik[3], l0[3], l1[3], b0[3], b1[3], z0[3], z1[3];
@@ -308,14 +374,15 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             phik[k] = d.phi[idxV(d, vk[k], t)];
-            b0[k] = d.bm[idxM(d, f * 3 + k, 0, c, t0)];
-            b1[k] = d.bm[idxM(d, f * 3 + k, 1, c, t1)];
+            b0[k] = d.bm[idxM(d, f * 3 + k, 0, c, t)];
+            b1[k] = d.bm[idxM(d, f * 3 + k, 1, c, t - 1)];
             if (ZMODE) {
-                l0[k] = d.lamc[idxV(d, vk[k], t0)];
-                l1[k] = d.lamc[idxV(d, vk[k], t1)];
+                l0[k] = d.lamc[idxV(d, vk[k], t)];
+                const double *pl = t > 0 ? d.lamc + idxV(d, vk[k], t - 1) : (has1 ? d.lamc_lo + vk[k] : d.lamc + idxV(d, vk[k], t));
+                l1[k] = *pl;
             } else {
-                z0[k] = d.zm[idxM(d, f * 3 + k, 0, c, t0)];
-                z1[k] = d.zm[idxM(d, f * 3 + k, 1, c, t1)];
+                z0[k] = d.zm[idxM(d, f * 3 + k, 0, c, t)];
+                z1[k] = d.zm[idxM(d, f * 3 + k, 1, c, t - 1)];
             }
         }
         double gx = 0.0;
@@ -338,15 +405,15 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
             S += (z0[k] + b0[k]) + (z1[k] + b1[k]);
         }
         const double Eo = d.E[ie];
-        const double Bn = (gx + Eo + sB * S) / ((t == 0 || t == d.T) ? diag_bd : diag_in);
+        const double Bn = (gx + Eo + sB * S) / ((first_node(d, t) || last_node(d, t)) ? diag_bd : diag_in);
         d.B[ie] = Bn;
         if (QONLY) continue;
         d.E[ie] = Eo + tau * (gx - Bn);
         const double sBn = sB * Bn;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            if (t < d.T) d.bm[idxM(d, f * 3 + k, 0, c, t)] = b0[k] + tau * (z0[k] - sBn);
-            if (t > 0) d.bm[idxM(d, f * 3 + k, 1, c, t - 1)] = b1[k] + tau * (z1[k] - sBn);
+            if (has0) d.bm[idxM(d, f * 3 + k, 0, c, t)] = b0[k] + tau * (z0[k] - sBn);
+            if (has1) d.bm[idxM(d, f * 3 + k, 1, c, t - 1)] = b1[k] + tau * (z1[k] - sBn);
         }
     }
 }
@@ -426,7 +493,7 @@ __global__ __launch_bounds__(BLOCK) void k_rebuild_mu(Dev d, double sz) {
     if (tile >= d.n_vtiles) return;
     for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
         const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (v >= d.V || t >= d.T) continue;
+        if (v >= d.V || t >= d.ni) continue;
         const int iv = idxV(d, v, t);
         d.mu[iv] = sz * (d.bf[iv] - d.be[iv]);
     }
@@ -435,8 +502,8 @@ __device__ __forceinline__ double dec_adjoint_at(const Dev &d, const double *x, 
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (t < d.T) s0 += x[idxM(d, f * 3 + k, 0, c, t)];
-        if (t > 0) s1 += x[idxM(d, f * 3 + k, 1, c, t - 1)];
+        if (t < d.ni) s0 += x[idxM(d, f * 3 + k, 0, c, t)];
+        if (has_prev_interval(d, t)) s1 += x[idxM(d, f * 3 + k, 1, c, t - 1)];
     }
     return s0 + s1;
 }
@@ -445,7 +512,7 @@ __global__ __launch_bounds__(BLOCK) void k_rebuild_E(Dev d, double sz) {
     if (tile >= d.n_ftiles) return;
     for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
         const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (row >= 3 * d.F || t > d.T) continue;
+        if (row >= 3 * d.F || t >= d.nl) continue;
         const int f = row / 3, c = row - 3 * f;
         d.E[idxF(d, f, c, t)] = -(sz * INV_SQRT3) * dec_adjoint_at(d, d.bm, f, c, t);
     }
@@ -464,34 +531,44 @@ int launch_scale_z(Ctx *c, double z_mul, double beta_mul, double sz_new) {
 // ------------------------------------------------------------------------------------------
 // layout conversion: reference layout (time-major) <-> device layout (time-fastest, permuted)
 // ------------------------------------------------------------------------------------------
+// Host layouts: one GPU -- the reference's (phi (T+1,V); interval arrays (T,V); B, E (T+1,F,3); z_mid, beta_mid (T,2,3,F,3)).
+// Time slab -- the same with the slab's time extent: (nl,V), (ni,V), (nl,F,3), and the corner arrays as (nl,2,3,F,3)
+// indexed by the NODE an entry belongs to (entry [j][s] is the reference's [t0 + j - s][s]; entries whose interval
+// does not exist are ignored on upload and zero on download).
 template <bool TO_DEV>
 __global__ __launch_bounds__(BLOCK) void k_convert(Dev d, int kind, double *dev, double *host) {
     // one thread per device element (t fastest -> device side coalesced; host side strided, staging only)
-    const int nt = (kind == 0 || kind == 2) ? d.T + 1 : d.T;
+    const int nt = (kind == 0 || kind == 2) ? d.nl : d.ni;
     const int64_t rows = (kind <= 1) ? d.V : (kind == 2 ? (int64_t)3 * d.F : (int64_t)18 * d.F);
     const int64_t n = rows << d.tp_shift;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         const int t = (int)(i & (d.TP - 1));
         const int64_t row = i >> d.tp_shift;
-        if (t >= nt) {
-            if (TO_DEV) dev[i] = 0.0;
-            continue;
-        }
         int64_t h;
         if (kind <= 1) {
+            if (t >= nt) { if (TO_DEV) dev[i] = 0.0; continue; }
             const int v = d.perm_v ? d.perm_v[row] : (int)row;
             h = (int64_t)t * d.V + v;
         } else if (kind == 2) {
+            if (t >= nt) { if (TO_DEV) dev[i] = 0.0; continue; }
             const int f = (int)(row / 3), c = (int)(row - 3 * (row / 3));
             const int fo = d.perm_f ? d.perm_f[f] : f;
             h = ((int64_t)t * d.F + fo) * 3 + c;
-        } else {  // row = ((f*3+k)*2+s)*3+c  ->  host [t][s][k][f][c]
+        } else {  // row = ((f*3+k)*2+s)*3+c, column t = node of the entry: interval t - s
             const int c = (int)(row % 3);
             const int s = (int)((row / 3) % 2);
             const int k = (int)((row / 6) % 3);
             const int f = (int)(row / 18);
             const int fo = d.perm_f ? d.perm_f[f] : f;
-            h = ((((int64_t)t * 2 + s) * 3 + k) * d.F + fo) * 3 + c;
+            const int ti = t - s, tg = d.t0 + ti;         // local / global interval of this slot
+            const bool valid = t < d.nl && tg >= 0 && tg < d.T;
+            if (!valid && !(d.slab && t < d.nl)) { if (TO_DEV) dev[i] = 0.0; continue; }
+            h = ((((int64_t)(d.slab ? t : ti) * 2 + s) * 3 + k) * d.F + fo) * 3 + c;
+            if (!valid) {       // a slab's host array has the slot, the interval does not exist
+                if (TO_DEV) dev[i] = 0.0;
+                else host[h] = 0.0;
+                continue;
+            }
         }
         if (TO_DEV) dev[i] = host[h];
         else host[h] = dev[i];
@@ -525,13 +602,13 @@ __global__ __launch_bounds__(BLOCK) void k_op_vertex(Dev d, int op, const double
         if (v >= d.V) continue;
         const int iv = idxV(d, v, t);
         if (op == DOTS_OP_GRAD_TIME) {
-            y[iv] = (t < d.T) ? (x[iv + 1] - x[iv]) * ih : 0.0;
+            y[iv] = (t < d.ni) ? (x[iv + 1] - x[iv]) * ih : 0.0;
         } else if (op == DOTS_OP_DIV_TIME || op == DOTS_OP_TIME_AVG_ADJOINT) {
-            if (t > d.T) { y[iv] = 0.0; continue; }
-            const double a = (t < d.T) ? x[iv] : 0.0, b = (t > 0) ? x[iv - 1] : 0.0;
+            if (t >= d.nl) { y[iv] = 0.0; continue; }
+            const double a = (t < d.ni) ? x[iv] : 0.0, b = (t > 0) ? x[iv - 1] : 0.0;
             y[iv] = (op == DOTS_OP_DIV_TIME) ? (a - b) * ih : 0.5 * (a + b);
         } else if (op == DOTS_OP_DIV_SPACE) {
-            if (t > d.T) { y[iv] = 0.0; continue; }
+            if (t >= d.nl) { y[iv] = 0.0; continue; }
             double ds = 0.0;
             for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
                 const int fk = d.cidx[j], f = fk / 3, k = fk - 3 * f;
@@ -548,7 +625,7 @@ __global__ __launch_bounds__(BLOCK) void k_op_triangle(Dev d, int op, double sca
     const double sB = scale * INV_SQRT3;
     for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
         const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (row >= 3 * d.F || t > d.T) continue;
+        if (row >= 3 * d.F || t >= d.nl) continue;
         const int f = row / 3, c = row - 3 * f;
         if (op == DOTS_OP_GRAD_SPACE) {
             double gx = 0.0;
@@ -559,7 +636,7 @@ __global__ __launch_bounds__(BLOCK) void k_op_triangle(Dev d, int op, double sca
             const double b = sB * x[idxF(d, f, c, t)];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                if (t < d.T) y[idxM(d, f * 3 + k, 0, c, t)] = b;
+                if (t < d.ni) y[idxM(d, f * 3 + k, 0, c, t)] = b;
                 if (t > 0) y[idxM(d, f * 3 + k, 1, c, t - 1)] = b;
             }
         } else if (op == DOTS_OP_DECOUPLE_ADJOINT) {
@@ -569,6 +646,7 @@ __global__ __launch_bounds__(BLOCK) void k_op_triangle(Dev d, int op, double sca
 }
 
 int launch_operator(Ctx *c, int op, double scale, const double *in, double *out) {
+    if (c->d.slab) { set_error("the standalone operators work on whole arrays: not available on a time slab"); return DOTS_ERR_STATE; }
     switch (op) {
         case DOTS_OP_GRAD_TIME:
         case DOTS_OP_DIV_TIME:

@@ -640,86 +640,81 @@ static int cg_core(Ctx *c, const double *b, double *x, dots_step_stats *stats) {
     return 0;
 }
 
-// Forward time-mode transform restricted to the modes [a0, a0 + dcg.cg_ncol) this context solves, written
-// with the PCG view's own pitch:  y[v][j] = sum_t Q[t][a0 + j] x[v][t].   Emits the column-0 partial sums
-// (mean removal of the singular mode) when asked to.
-__global__ __launch_bounds__(BLOCK) void k_time_modes_fwd_sub(Dev d, Dev g, int a0, const double *__restrict__ x, double *__restrict__ y,
-                                                            int emit_col0) {
+// ---- transforms of a time-slab context (multi-GPU) -------------------------------------------------------------
+// Both read an all-gathered buffer of R chunks: chunk p holds [V][pitch] doubles with `stride` live columns, column j of
+// chunk p = global index p * stride + j (time node for the right-hand side, time mode for the solution).
+struct Gathered {
+    const double *base;
+    int64_t chunk;       // doubles per rank
+    int shift;           // log2 of the pitch inside a chunk
+    int stride;          // live columns per chunk
+};
+__device__ __forceinline__ double gathered_at(const Gathered &G, int v, int i) {
+    const int p = i / G.stride, j = i - p * G.stride;
+    return G.base[p * G.chunk + ((int64_t)v << G.shift) + j];
+}
+
+// Forward transform restricted to the modes [a0, a0 + g.cg_ncol) this context solves, from the gathered right-hand
+// side:  y[v][j] = sum_t Q[t][a0 + j] b[v][t]  (pitch of the PCG view).  Emits the column-0 partial sums (mean removal
+// of the singular mode) when asked to.   dt: the global-time view (T, Q).
+__global__ __launch_bounds__(BLOCK) void k_time_modes_fwd_sub(Dev dt, Dev g, int a0, Gathered x, double *__restrict__ y, int emit_col0) {
     __shared__ double lds[4];
-    const int n = d.T + 1, nloc = g.cg_ncol;
+    const int n = dt.T + 1, nloc = g.cg_ncol;
     double part[1] = {0.0};
-    const int64_t total = (int64_t)d.V << g.tp_shift;
+    const int64_t total = (int64_t)dt.V << g.tp_shift;
     for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
         const int v = (int)(e >> g.tp_shift), j = (int)(e & (g.TP - 1));
         if (j >= nloc) continue;
-        const double *row = x + idxV(d, v, 0);
         double s = 0.0;
-        for (int i = 0; i < n; ++i) s += d.Q[i * n + a0 + j] * row[i];
+        for (int i = 0; i < n; ++i) s += dt.Q[i * n + a0 + j] * gathered_at(x, v, i);
         y[idxV(g, v, j)] = s;
         if (emit_col0 && j == 0) part[0] += s;
     }
     if (emit_col0) {
         block_sum<1>(part, lds);
-        if (threadIdx.x == 0) d.partials[blockIdx.x] = part[0];
+        if (threadIdx.x == 0) dt.partials[blockIdx.x] = part[0];
     }
 }
 
-// Inverse transform from the gathered mode-space solution of all ranks: gathered[p][v][j] holds mode
-// p * nloc + j with pitch tpl.   phi[v][t] = sum_a Q[t][a] xhat[a][v]
-__global__ __launch_bounds__(BLOCK) void k_time_modes_inv_gathered(Dev d, const double *__restrict__ gathered, int nloc, int tpl_shift,
-                                                                 double *__restrict__ y) {
-    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
-    const int n = d.T + 1;
-    if (tile >= d.n_vtiles) return;
-    const int64_t rank_stride = (int64_t)d.V << tpl_shift;
-    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
-        const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (v >= d.V || t >= n) continue;
-        double s = 0.0;
-        for (int a = 0; a < n; ++a) {
-            const int p = a / nloc, j = a - p * nloc;
-            s += d.Q[t * n + a] * gathered[p * rank_stride + ((int64_t)v << tpl_shift) + j];
-        }
-        y[idxV(d, v, t)] = s;
-    }
-}
-
-// Tiled forms of the two sharded transforms (same staging as k_time_modes_tile): the forward one stores only this
-// context's modes [a0, a0 + nloc) with the PCG view's pitch; the inverse one stages its tile from the gathered buffer.
-__global__ __launch_bounds__(BLOCK) void k_time_modes_fwd_sub_tile(Dev d, int a0, int nloc, int out_shift, const double *__restrict__ x,
-                                                                   double *__restrict__ y, int IC) {
+// Tiled forms (same staging as k_time_modes_tile; dt = the global-time view: pitch >= T + 1).  Forward: stores only
+// this context's modes with the PCG view's pitch.
+__global__ __launch_bounds__(BLOCK) void k_time_modes_fwd_sub_tile(Dev dt, int a0, int nloc, int out_shift, Gathered x, double *__restrict__ y, int IC) {
     extern __shared__ double tm_lds[];
-    const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+    const int n = dt.T + 1, TP = dt.TP, TPp = TP + 1;
     double *Qs = tm_lds, *xs = tm_lds + IC * TP;
-    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
-    if (tile >= d.n_vtiles) return;
-    const int v0 = tile * d.VT;
+    const int tile = xcd_tile(blockIdx.x, dt.n_vtiles);
+    if (tile >= dt.n_vtiles) return;
+    const int v0 = tile * dt.VT;
     for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
-        const int vl = e >> d.tp_shift, t = e & (TP - 1);
-        xs[vl * TPp + t] = (v0 + vl < d.V && t < n) ? x[idxV(d, v0 + vl, t)] : 0.0;
+        const int vl = e >> dt.tp_shift, t = e & (TP - 1);
+        xs[vl * TPp + t] = (v0 + vl < dt.V && t < n) ? gathered_at(x, v0 + vl, t) : 0.0;
     }
-    modes_from_tile<true>(d, d.Q, xs, Qs, IC, v0, y, out_shift, a0, nloc);
+    modes_from_tile<true>(dt, dt.Q, xs, Qs, IC, v0, y, out_shift, a0, nloc);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_time_modes_inv_gathered_tile(Dev d, const double *__restrict__ gathered, int nloc, int tpl_shift,
-                                                                        double *__restrict__ y, int IC) {
+// Inverse: phi of this slab's nodes [t0, t0 + nl) (pitch of the slab, 1 << out_shift) from the gathered mode-space
+// solution, and phi at node t0 + nl (the next slab's first node) into phi_hi: the same sum, in the same order, as the
+// owner of that node forms -- no exchange of phi is ever needed.
+__global__ __launch_bounds__(BLOCK) void k_time_modes_inv_gathered_tile(Dev dt, Gathered x, double *__restrict__ y, int out_shift, int t0, int nl,
+                                                                        double *__restrict__ phi_hi, int IC) {
     extern __shared__ double tm_lds[];
-    const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+    const int n = dt.T + 1, TP = dt.TP, TPp = TP + 1;
     double *Qs = tm_lds, *xs = tm_lds + IC * TP;
-    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
-    if (tile >= d.n_vtiles) return;
-    const int v0 = tile * d.VT;
-    const int64_t rank_stride = (int64_t)d.V << tpl_shift;
+    const int tile = xcd_tile(blockIdx.x, dt.n_vtiles);
+    if (tile >= dt.n_vtiles) return;
+    const int v0 = tile * dt.VT;
     for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
-        const int vl = e >> d.tp_shift, a = e & (TP - 1);
-        double val = 0.0;
-        if (v0 + vl < d.V && a < n) {
-            const int p = a / nloc, j = a - p * nloc;
-            val = gathered[p * rank_stride + ((int64_t)(v0 + vl) << tpl_shift) + j];
-        }
-        xs[vl * TPp + a] = val;
+        const int vl = e >> dt.tp_shift, a = e & (TP - 1);
+        xs[vl * TPp + a] = (v0 + vl < dt.V && a < n) ? gathered_at(x, v0 + vl, a) : 0.0;
     }
-    modes_from_tile<false>(d, d.Q, xs, Qs, IC, v0, y);
+    modes_from_tile<false>(dt, dt.Q, xs, Qs, IC, v0, y, out_shift, t0, nl);
+    const int th = t0 + nl;      // first node of the next slab
+    if (th < n && (int)threadIdx.x < dt.VT && v0 + (int)threadIdx.x < dt.V) {
+        const double *x0 = xs + threadIdx.x * TPp;
+        double acc = 0.0;
+        for (int a = 0; a < n; ++a) acc += dt.Q[th * n + a] * x0[a];
+        phi_hi[v0 + threadIdx.x] = acc;
+    }
 }
 
 // Step 1 for the modes of this context.  Unsharded: also transforms back (phi is complete on return).
@@ -737,13 +732,16 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats, bool defer_inverse) {
     if (MODAL && g.cg_ncol == 0) return 0;   // a rank without modes has nothing to solve
     const bool direct = MODAL && c->use_front && c->front.n_nodes > 0;   // no warm start, no mean removal needed
     if (sharded) {
+        // time-slab context: the right-hand side of ALL nodes was all-gathered into slab.b_recv; this rank transforms the
+        // modes it solves.  The PCG warm start is its own mode-space solution of the previous iteration (g.cg_x).
+        const Dev &dt = c->dgt;
+        const Gathered bg{c->slab.b_recv, c->slab_b_chunk, d.tp_shift, c->shard_stride};
         const int gs = 1024;   // grid-stride; k_cg_bmean sums exactly this many partial sums
-        if (direct && time_modes_tile_ok(d))     // no mean removal with the direct solver: the tiled transform
-            hipLaunchKernelGGL(k_time_modes_fwd_sub_tile, dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, c->shard_begin, g.cg_ncol, g.tp_shift,
-                               d.cg_b, g.cg_p0, time_modes_chunk(d));
+        if (direct && time_modes_tile_ok(dt))     // no mean removal with the direct solver: the tiled transform
+            hipLaunchKernelGGL(k_time_modes_fwd_sub_tile, dim3(xcd_grid(dt.n_vtiles)), dim3(BLOCK), time_modes_tile_lds(dt), c->stream, dt, c->shard_begin,
+                               g.cg_ncol, g.tp_shift, bg, g.cg_p0, time_modes_chunk(dt));
         else
-            hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.cg_b, g.cg_p0, owns_mode0 ? 1 : 0);
-        if (!direct) hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, d, g, c->shard_begin, d.phi, g.cg_x, 0);
+            hipLaunchKernelGGL(k_time_modes_fwd_sub, dim3(gs), dim3(BLOCK), 0, c->stream, dt, g, c->shard_begin, bg, g.cg_p0, owns_mode0 ? 1 : 0);
         b = g.cg_p0;
         const double mean_scale = (singular && owns_mode0) ? 1.0 / d.V : 0.0;
         if (!direct) hipLaunchKernelGGL(k_cg_bmean, dim3(1), dim3(BLOCK), 0, c->stream, d, owns_mode0 ? gs : 0, g.cg_ncol, mean_scale);
@@ -790,15 +788,14 @@ int cg_solve(Ctx *c, dots_step_stats *stats, bool defer_inverse) {
     return c->lap_solver == DOTS_LAP_MODAL_PCG ? cg_solve_impl<true>(c, stats, defer_inverse) : cg_solve_impl<false>(c, stats, false);
 }
 
-// phi from the mode-space solutions of all ranks (device buffer [n_ranks][V][local pitch])
-int cg_finish_sharded(Ctx *c, const double *gathered) {
-    const Dev &d = c->d;
-    if (time_modes_tile_ok(d))
-        hipLaunchKernelGGL(k_time_modes_inv_gathered_tile, dim3(xcd_grid(d.n_vtiles)), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, gathered,
-                           c->shard_stride, c->dcg.tp_shift, d.phi, time_modes_chunk(d));
-    else
-        hipLaunchKernelGGL(k_time_modes_inv_gathered, dim3(xcd_grid(d.n_vtiles)), dim3(BLOCK), 0, c->stream, d, gathered, c->shard_stride,
-                           c->dcg.tp_shift, d.phi);
+// phi of this slab from the mode-space solutions of all ranks (slab.x_recv = [n_ranks][V][mode pitch])
+int cg_finish_sharded(Ctx *c) {
+    const Dev &d = c->d, &dt = c->dgt;
+    if (d.nl == 0) return 0;
+    if (!time_modes_tile_ok(dt)) { set_error("time slabs need T + 1 <= 256"); return DOTS_ERR_STATE; }
+    const Gathered xg{c->slab.x_recv, (int64_t)d.V << c->dcg.tp_shift, c->dcg.tp_shift, c->shard_stride};
+    hipLaunchKernelGGL(k_time_modes_inv_gathered_tile, dim3(xcd_grid(dt.n_vtiles)), dim3(BLOCK), time_modes_tile_lds(dt), c->stream, dt, xg, d.phi,
+                       d.tp_shift, d.t0, d.nl, d.phi_hi, time_modes_chunk(dt));
     DOTS_HIP(hipGetLastError());
     return 0;
 }

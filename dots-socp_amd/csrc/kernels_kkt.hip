@@ -37,13 +37,13 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_vertex(Dev d, KktArgs a) {
         const double ih = 1.0 / d.h, rho_s = a.ds * a.r;
         for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
             const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-            if (v >= d.V || t > d.T) continue;
+            if (v >= d.V || t >= d.nl) continue;
             const int iv = idxV(d, v, t);
             const double m = d.mass_v[v];
-            if (t < d.T) {
+            if (t < d.ni) {
                 const double A = d.A[iv], mu = d.mu[iv], lc = d.lam[iv];
                 if (c0) {   // Prim(phi, q): solver_socp.py:433-450, residuals of :592-593
-                    const double dphi = (d.phi[iv + 1] - d.phi[iv]) * ih;
+                    const double dphi = (next_node(d, d.phi, d.phi_hi, v, t) - d.phi[iv]) * ih;
                     const double rm = dphi - A - lc;
                     s[V_DPHI2] += dphi * dphi * m;
                     s[V_A2] += A * A * m;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_vertex(Dev d, KktArgs a) {
                         double sq = 0.0;
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            const double b0 = a.ps * d.B[idxF(d, f, c, t)], b1 = a.ps * d.B[idxF(d, f, c, t + 1)];
+                            const double b0 = a.ps * d.B[idxF(d, f, c, t)], b1 = a.ps * next_node(d, d.B, d.B_hi, f * 3 + c, t);
                             sq += b0 * b0 + b1 * b1;
                         }
                         q += d.c_area[j] * sq * (1.0 / 3.0);
@@ -86,8 +86,9 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_vertex(Dev d, KktArgs a) {
             }
             if (c2) {       // Dual(alpha): :466-482
                 double x = 0.0;
-                if (t < d.T) x += d.mu[iv] * m;
+                if (t < d.ni) x += d.mu[iv] * m;
                 if (t > 0) x -= d.mu[iv - 1] * m;
+                else if (has_prev_interval(d, t)) x -= d.mu_lo[v] * m;
                 x *= ih;
                 double dsx = 0.0;
                 for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_vertex(Dev d, KktArgs a) {
                     for (int c = 0; c < 3; ++c) dsx += d.c_gA[j * 3 + c] * d.E[idxF(d, f, c, t)];
                 }
                 x -= dsx;
-                if (t == 0) x -= a.bs * d.mu0[v] / (a.r * d.h);
-                if (t == d.T) x += a.bs * d.mu1[v] / (a.r * d.h);
+                if (first_node(d, t)) x -= a.bs * d.mu0[v] / (a.r * d.h);
+                if (last_node(d, t)) x += a.bs * d.mu1[v] / (a.r * d.h);
                 const double aux = (a.r * d.h) * x / m;
                 s[V_DUALAUX2] += aux * aux * m;
             }
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_triangle(Dev d, KktArgs a, double
         const double sB = a.sz * INV_SQRT3, rho_s = a.ds * a.r;
         for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
             const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
-            if (row >= 3 * d.F || t > d.T) continue;
+            if (row >= 3 * d.F || t >= d.nl) continue;
             const int f = row / 3, c = row - 3 * f;
             const double w = d.area_f[f];
             const int64_t ie = idxF(d, f, c, t);
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_triangle(Dev d, KktArgs a, double
                     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        if (t < d.T) s0 += d.bm[idxM(d, f * 3 + k, 0, c, t)];
-                        if (t > 0) s1 += d.bm[idxM(d, f * 3 + k, 1, c, t - 1)];
+                        if (t < d.ni) s0 += d.bm[idxM(d, f * 3 + k, 0, c, t)];
+                        if (has_prev_interval(d, t)) s1 += d.bm[idxM(d, f * 3 + k, 1, c, t - 1)];
                     }
                     const double a2 = sB * (s0 + s1);
                     s[F_AUX2_2 - N_VSUMS] += a2 * a2 * w;
@@ -152,10 +153,12 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_triangle(Dev d, KktArgs a, double
                     double rn = 0.0;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const int iv = idxV(d, d.tri[f * 3 + k], t);
+                        const int vk = d.tri[f * 3 + k];
+                        const int iv = idxV(d, vk, t);
                         double r2 = 0.0;
-                        if (t < d.T) r2 += d.mu[iv];
+                        if (t < d.ni) r2 += d.mu[iv];
                         if (t > 0) r2 += d.mu[iv - 1];
+                        else if (has_prev_interval(d, t)) r2 += d.mu_lo[vk];
                         rn += 0.5 * rho_s * r2;
                     }
                     const double aux = (rn * (1.0 / 3.0)) * (a.ps * B);
@@ -168,11 +171,11 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_triangle(Dev d, KktArgs a, double
                 const double sb = sB * B;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    if (t < d.T) {
+                    if (t < d.ni) {
                         const double q = a.sz * (d.zm[idxM(d, f * 3 + k, 0, c, t)] - sb);
                         s[F_RMID2 - N_VSUMS] += q * q * w;
                     }
-                    if (t > 0) {
+                    if (has_prev_interval(d, t)) {
                         const double q = a.sz * (d.zm[idxM(d, f * 3 + k, 1, c, t - 1)] - sb);
                         s[F_RMID2 - N_VSUMS] += q * q * w;
                     }
@@ -208,13 +211,16 @@ static int fetch_sums(Ctx *c, int n) {
     return 0;
 }
 
-int kkt_evaluate(Ctx *c, uint32_t mask, double *out) {
+// The weighted sums the conditions in `mask` need (of this context's time slab; the whole problem on one GPU).
+int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
     const Dev &d = c->d;
     const dots_params &p = c->prm;
     KktArgs a{mask, p.r, p.scale_z, p.const_d, p.congestion, p.prim_scale, p.dual_scale, p.boundary_scale};
     const int gv = xcd_grid(d.n_vtiles), gf = xcd_grid(d.n_ftiles);
     double *part_f = d.partials + (int64_t)N_VSUMS * gv;
     const bool need_v = mask & (1u | 2u | 4u | 8u | 16u | 64u), need_f = mask & (1u | 2u | 8u | 32u);
+    for (int i = 0; i < N_SUMS; ++i) sums[i] = 0.0;
+    if (d.nl == 0) return 0;          // a rank without nodes contributes nothing
     if (need_v) {
         hipLaunchKernelGGL(k_kkt_vertex, dim3(gv), dim3(BLOCK), 0, c->stream, d, a);
         int rc = reduce_partials(c, d.partials, N_VSUMS, gv, 0);
@@ -228,7 +234,24 @@ int kkt_evaluate(Ctx *c, uint32_t mask, double *out) {
     DOTS_HIP(hipGetLastError());
     int rc = fetch_sums(c, N_SUMS);
     if (rc) return rc;
-    const double *s = c->h_pinned;
+    // slots of kernels that did not run hold leftovers of earlier calls: report zeros there
+    for (int i = 0; i < N_SUMS; ++i) sums[i] = ((i < N_VSUMS) ? need_v : need_f) ? c->h_pinned[i] : 0.0;
+    return 0;
+}
+
+int kkt_n_sums() { return N_SUMS; }
+
+int kkt_evaluate(Ctx *c, uint32_t mask, double *out) {
+    double sums[N_SUMS];
+    int rc = kkt_sums(c, mask, sums);
+    if (rc) return rc;
+    return kkt_combine(c, mask, sums, out);
+}
+
+// The reference's closures (solver_socp.py:433-559) on the sums of the WHOLE problem.
+int kkt_combine(Ctx *c, uint32_t mask, const double *s, double *out) {
+    const Dev &d = c->d;
+    const dots_params &p = c->prm;
     const double T = d.T, T1 = d.T + 1;
     auto nt = [&](int i) { return s[i] / T; };     // norm_square_time
     auto nc = [&](int i) { return s[i] / T1; };    // norm_square_center
@@ -287,11 +310,11 @@ __global__ __launch_bounds__(BLOCK) void k_objective(Dev d) {
     if (tile < d.n_vtiles) {
         for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
             const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-            if (v >= d.V || t > d.T) continue;
+            if (v >= d.V || t >= d.nl) continue;
             const int iv = idxV(d, v, t);
-            if (t == 0) s[0] += d.phi[iv] * d.mu0[v];
-            if (t == d.T) s[1] += d.phi[iv] * d.mu1[v];
-            if (t < d.T) s[2] += d.lam[iv] * d.lam[iv] * d.mass_v[v];
+            if (first_node(d, t)) s[0] += d.phi[iv] * d.mu0[v];
+            if (last_node(d, t)) s[1] += d.phi[iv] * d.mu1[v];
+            if (t < d.ni) s[2] += d.lam[iv] * d.lam[iv] * d.mass_v[v];
         }
     }
     block_sum<3>(s, lds);
@@ -299,21 +322,35 @@ __global__ __launch_bounds__(BLOCK) void k_objective(Dev d) {
         for (int i = 0; i < 3; ++i) d.partials[(int64_t)i * gridDim.x + blockIdx.x] = s[i];
 }
 
-int objective_evaluate(Ctx *c, double *out) {
+int objective_sums(Ctx *c, double *sums) {
     const Dev &d = c->d;
-    const dots_params &p = c->prm;
+    sums[0] = sums[1] = sums[2] = 0.0;
+    if (d.nl == 0) return 0;
     const int gv = xcd_grid(d.n_vtiles);
     hipLaunchKernelGGL(k_objective, dim3(gv), dim3(BLOCK), 0, c->stream, d);
     int rc = reduce_partials(c, d.partials, 3, gv, 0);
     if (rc) return rc;
     rc = fetch_sums(c, 3);
     if (rc) return rc;
-    const double *s = c->h_pinned;
+    for (int i = 0; i < 3; ++i) sums[i] = c->h_pinned[i];
+    return 0;
+}
+
+int objective_combine(Ctx *c, const double *s, double *out) {
+    const Dev &d = c->d;
+    const dots_params &p = c->prm;
     const double cost = p.prim_scale * p.dual_scale * p.boundary_scale * (s[1] - s[0]);
     const double cong = p.congestion * p.prim_scale / p.dual_scale;
     out[0] = cost;
     out[1] = (cong > 1e-10) ? cost - (p.prim_scale * p.prim_scale * s[2] / d.T) / (2.0 * cong) : cost;
     return 0;
+}
+
+int objective_evaluate(Ctx *c, double *out) {
+    double s[3];
+    int rc = objective_sums(c, s);
+    if (rc) return rc;
+    return objective_combine(c, s, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -335,19 +372,19 @@ __global__ __launch_bounds__(BLOCK) void k_norm(Dev d, const double *x, int kind
                 const int iv = idxV(d, (int)row, t);
                 double val = 0.0;
                 if (part == 1) {
-                    if (t >= d.T) continue;
-                    val = (x[iv + 1] - x[iv]) / d.h;
+                    if (t >= d.ni) continue;
+                    val = (next_node(d, x, d.phi_hi, row, t) - x[iv]) / d.h;
                 } else {
-                    if (t >= (kind == 0 ? d.T + 1 : d.T)) continue;
+                    if (t >= (kind == 0 ? d.nl : d.ni)) continue;
                     val = x[iv];
                 }
                 s[0] += val * val * d.mass_v[row];
             } else if (kind == 3) {
-                if (row >= (int64_t)18 * d.F || t >= d.T) continue;
+                if (row >= (int64_t)18 * d.F || t >= d.nl) continue;      // slots without an interval hold zeros
                 const double val = x[(row << d.tp_shift) + t];
                 s[0] += val * val * d.area_f[row / 18];
             } else {
-                if (row >= (int64_t)3 * d.F || t > d.T) continue;
+                if (row >= (int64_t)3 * d.F || t >= d.nl) continue;
                 const int f = (int)(row / 3), c = (int)(row - 3 * (row / 3));
                 double val;
                 if (part == 2) {
@@ -366,6 +403,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm(Dev d, const double *x, int kind
 
 int norm_square(Ctx *c, int id, int part, double *out) {
     const Dev &d = c->d;
+    if (d.slab) { set_error("norm_square works on whole arrays: not available on a time slab"); return DOTS_ERR_STATE; }
     const int kind = array_kind(id);
     if (part != 0 && id != DOTS_PHI) {
         set_error("part != 0 is only defined for DOTS_PHI");

@@ -22,9 +22,10 @@ def _ptr(a, ctype):
 
 class DeviceProblem:
     def __init__(self, n_time, geometry, lap_solver="spacetime_pcg", device=0, reorder=True, plan: DevicePlan | None = None,
-                 mode_shard=None, nd_leaf=16):
-        """``mode_shard = (rank, n_ranks)``: this context solves only its slice of the T+1 time modes
-        (multi-GPU, see distributed.py); the caller then drives ``step_begin`` / ``step_end``."""
+                 time_slab=None, nd_leaf=16):
+        """``time_slab = (rank, n_ranks)``: this context is one TIME SLAB of a multi-GPU solve (distributed.py): it holds
+        the nodes [rank * stride, ...) of every state array and solves the time modes with the same indices; the caller
+        drives ``slab_stage`` around its exchanges."""
         self.lib = _lib.load()
         self.plan = plan if plan is not None else build_plan(n_time, geometry, reorder=reorder, nd_leaf=nd_leaf)
         p = self.plan
@@ -55,14 +56,18 @@ class DeviceProblem:
         d.time_modes = _ptr(p.time_modes, C.c_double)
         d.time_eigs = _ptr(p.time_eigs, C.c_double)
         self.mode_slice = None
-        if mode_shard is not None:
-            rank, n_ranks = mode_shard
+        self.node0, self.nl, self.ni = 0, p.n_time + 1, p.n_time
+        self.slab = None
+        if time_slab is not None:
+            rank, n_ranks = time_slab
             stride = -(-(p.n_time + 1) // n_ranks)
             begin = min(rank * stride, p.n_time + 1)
             count = max(0, min(stride, p.n_time + 1 - begin))
-            d.mode_begin, d.mode_count, d.mode_stride = begin, count, stride
-            self.mode_slice = slice(begin, begin + count)
-            self.mode_stride, self.n_ranks = stride, n_ranks
+            d.slab_begin, d.slab_count, d.slab_stride = (begin if count else 0), count, stride
+            self.mode_slice = slice(begin, begin + count)       # modes solved here = nodes held here
+            self.slab = (rank, n_ranks, stride)
+            self.node0, self.nl, self.ni = begin, count, max(0, min(count, p.n_time - begin))
+            self.active_ranks = -(-(p.n_time + 1) // stride)    # ranks that hold at least one node
         self._h = C.c_void_p()
         _lib.check(self.lib.dots_create(C.byref(d), C.byref(self._h)), "dots_create")
         self.params = _lib.Params()
@@ -86,16 +91,44 @@ class DeviceProblem:
     def __exit__(self, *exc):
         self.close()
 
-    # ---- shapes of the reference layouts
+    # ---- shapes of the host arrays: the reference layouts on one GPU, the slab's time extent on a time slab
     def shape(self, name):
-        T, V, F = self.T, self.V, self.F
+        V, F = self.V, self.F
         if name == "phi":
-            return (T + 1, V)
+            return (self.nl, V)
         if name in ("B", "E"):
-            return (T + 1, F, 3)
+            return (self.nl, F, 3)
         if name in ("z_mid", "beta_mid"):
-            return (T, 2, 3, F, 3)
-        return (T, V)
+            return ((self.nl if self.slab else self.ni), 2, 3, F, 3)
+        return (self.ni, V)
+
+    def full_shape(self, name):
+        T, V, F = self.T, self.V, self.F
+        return {"phi": (T + 1, V), "B": (T + 1, F, 3), "E": (T + 1, F, 3), "z_mid": (T, 2, 3, F, 3), "beta_mid": (T, 2, 3, F, 3)}.get(name, (T, V))
+
+    def to_slab(self, name, full):
+        """This slab's part of a whole array in the reference layout (see include/dots_socp_hip.h: the corner arrays
+        are indexed by the node an entry is compared with)."""
+        full = np.asarray(full, dtype=np.float64)
+        n0, nl, ni = self.node0, self.nl, self.ni
+        if name in ("z_mid", "beta_mid"):
+            out = np.zeros(self.shape(name))
+            out[:ni, 0] = full[n0:n0 + ni, 0]
+            lo = 1 if n0 == 0 else 0                           # entry [j][1] is the reference's [n0 + j - 1][1]
+            out[lo:nl, 1] = full[n0 + lo - 1:n0 + nl - 1, 1]
+            return out
+        return np.ascontiguousarray(full[n0:n0 + (nl if name in ("phi", "B", "E") else ni)])
+
+    def from_slab(self, name, part, full):
+        """Write this slab's part into a whole array in the reference layout (entries of other slabs untouched)."""
+        n0, nl, ni = self.node0, self.nl, self.ni
+        if name in ("z_mid", "beta_mid"):
+            full[n0:n0 + ni, 0] = part[:ni, 0]
+            lo = 1 if n0 == 0 else 0
+            full[n0 + lo - 1:n0 + nl - 1, 1] = part[lo:nl, 1]
+        else:
+            full[n0:n0 + part.shape[0]] = part
+        return full
 
     # ---- parameters
     def set_params(self, **kw):
@@ -134,21 +167,20 @@ class DeviceProblem:
         flags = (_lib.STEP_SKIP_Z_MID if skip_z_mid else 0) | (_lib.STEP_PALM if palm else 0)
         _lib.check(self.lib.dots_step_flags(self._h, flags), "dots_step_flags")
 
-    # ---- sharded iteration (multi-GPU): begin -> all-gather by the caller -> end
-    def shard_elems(self):
-        return int(self.lib.dots_shard_elems(self._h))
+    # ---- time slab (multi-GPU): stages of one iteration around the caller's exchanges (dots_slab_stage)
+    def slab_elems(self, which):
+        return int(self.lib.dots_slab_elems(self._h, _lib.SLAB_SIZES[which]))
 
-    def step_begin(self, send_ptr, count, wait=True):
-        """Right-hand side + solve for this context's modes; the result is copied to device memory at send_ptr.
-        ``wait=False``: only enqueue (order the exchange with ``stream_wait``); returns None."""
-        st = _lib.StepStats() if wait else None
-        _lib.check(self.lib.dots_step_begin(self._h, C.c_void_p(int(send_ptr)), int(count), C.byref(st) if wait else None), "dots_step_begin")
-        return st
+    def slab_set_buffers(self, **pointers):
+        b = _lib.SlabBuffers()
+        for name in _lib.SlabBuffers.NAMES:
+            setattr(b, name, int(pointers[name]))
+        _lib.check(self.lib.dots_slab_set_buffers(self._h, C.byref(b)), "dots_slab_set_buffers")
 
-    def step_end(self, recv_ptr, count, wait=True):
-        """Inverse time transform from the gathered buffer at recv_ptr, then steps 1-2, 2 and 3."""
+    def slab_stage(self, stage, wait=False):
+        """``wait=False``: only enqueue on the context's stream (order the exchange with ``stream_wait``)."""
         st = _lib.StepStats() if wait else None
-        _lib.check(self.lib.dots_step_end(self._h, C.c_void_p(int(recv_ptr)), int(count), C.byref(st) if wait else None), "dots_step_end")
+        _lib.check(self.lib.dots_slab_stage(self._h, int(stage), C.byref(st) if wait else None), f"dots_slab_stage {stage}")
         return st
 
     def stream_wait(self, other_stream, ctx_waits):
@@ -173,9 +205,39 @@ class DeviceProblem:
             res[int(i)] = [float(out[2 * i]), None if i >= 4 else second]
         return res
 
+    @staticmethod
+    def _mask(conditions):
+        mask = 0
+        for i in conditions:
+            mask |= 1 << int(i)
+        return mask
+
+    def kkt_sums(self, conditions):
+        """The weighted sums of this context's time slab that the listed conditions need (to be added over the slabs)."""
+        sums = np.zeros(_lib.KKT_N_SUMS)
+        _lib.check(self.lib.dots_kkt_sums(self._h, self._mask(conditions), _ptr(sums, C.c_double)), "dots_kkt_sums")
+        return sums
+
+    def kkt_combine(self, conditions, sums):
+        """The listed KKT residuals from the sums of the whole problem; same return value as ``kkt``."""
+        out = np.full(14, np.nan)
+        sums = np.ascontiguousarray(sums, dtype=np.float64)
+        _lib.check(self.lib.dots_kkt_combine(self._h, self._mask(conditions), _ptr(sums, C.c_double), _ptr(out, C.c_double)), "dots_kkt_combine")
+        return {int(i): [float(out[2 * i]), None if i >= 4 else float(out[2 * i + 1])] for i in conditions}
+
     def objective(self):
         out = np.zeros(2)
         _lib.check(self.lib.dots_objective(self._h, _ptr(out, C.c_double)), "dots_objective")
+        return float(out[0]), float(out[1])
+
+    def objective_sums(self):
+        sums = np.zeros(3)
+        _lib.check(self.lib.dots_objective_sums(self._h, _ptr(sums, C.c_double)), "dots_objective_sums")
+        return sums
+
+    def objective_combine(self, sums):
+        out, sums = np.zeros(2), np.ascontiguousarray(sums, dtype=np.float64)
+        _lib.check(self.lib.dots_objective_combine(self._h, _ptr(sums, C.c_double), _ptr(out, C.c_double)), "dots_objective_combine")
         return float(out[0]), float(out[1])
 
     def adjust_penalty(self, factor):

@@ -65,7 +65,7 @@ class AlmSolver:
     def __init__(self, n_time, geometry, congestion=0.0, nit=1000, eps=0.0, tol=1e-4, tau=1.90, is_z_scaling=True,
                  is_constant_scaling=False, check_kkt_step_by_step=False, init_solution=None, tol_checkpoints=None,
                  time_limit=1000, is_palm=False, lap_solver="modal_direct", cg_tol=DEFAULT_CG_TOL, cg_max_iter=20000, device=0, reorder=True,
-                 preconditioner="multigrid", mg_coarsest=256, mode_shard=None, nd_leaf=16):
+                 preconditioner="multigrid", mg_coarsest=256, time_slab=None, nd_leaf=16):
         self.tol_checkpoints = _validate_checkpoints(tol_checkpoints, tol)
         self.checkpoint_solutions = []
         self.n_time, self.nit, self.tol, self.time_limit = int(n_time), int(nit), tol, time_limit
@@ -77,7 +77,7 @@ class AlmSolver:
         if direct and reorder is True:
             reorder = "nd"      # the elimination order of the factor doubles as the locality numbering
         self.dev = dev = DeviceProblem(n_time, geometry, lap_solver="modal_pcg" if direct else lap_solver, device=device,
-                                       reorder=reorder, mode_shard=mode_shard, nd_leaf=nd_leaf)
+                                       reorder=reorder, time_slab=time_slab, nd_leaf=nd_leaf)
 
         p = dev.params
         self.r = 1.0
@@ -114,7 +114,7 @@ class AlmSolver:
         if is_constant_scaling:
             self._initial_constant_scaling(init_solution)                # :574-586
 
-        conditions = [ErrorCondition((lambda i=i: dev.kkt([i])[i]), tol, KKT_SHORT_LABELS[i]) for i in range(7)]
+        conditions = [ErrorCondition((lambda i=i: self._kkt([i])[i]), tol, KKT_SHORT_LABELS[i]) for i in range(7)]
         self.kkt_validator = AdaptiveValidator(ConditionValidator(conditions, KKT_QUEUE_ORDER))   # :589-645
         self.start_time = time.perf_counter()
 
@@ -226,6 +226,17 @@ class AlmSolver:
             return (self.r * self.dual_scale) * arr
         return (self.r * self.scale_z * self.dual_scale) * arr
 
+    # ---- what the multi-GPU solver overrides: everything that reads numbers or arrays back from the device(s)
+    def _kkt(self, conditions):
+        return self.dev.kkt(conditions)
+
+    def _objective(self):
+        return self.dev.objective()
+
+    def _download(self, name):
+        """The whole array ``name`` in the reference layout."""
+        return self.dev.download(name)
+
     def _device_step(self, quiet=False):
         """Steps 1-3 on the device; the multi-GPU solver overrides this with begin / all-gather / end.
 
@@ -292,15 +303,15 @@ class AlmSolver:
         else:
             passed, _info = validator.validator.validate(list(range(7)))
             org, scaled = validator.collect()
-            cost, lagr = dev.objective()
+            cost, lagr = self._objective()
             hist.record(current_it=it, kkt_errors=org, history={"Transportation cost": cost, "Objective value": lagr})
             error = max_of_list_with_none([org[i] for i in KKT_STOP])
 
         cps = self.tol_checkpoints
         if cps and error is not None and error <= cps[0]:                      # :790-801
             self.checkpoint_solutions.append({
-                "mu": (self.r * self.dual_scale) * dev.download("mu"),
-                "E": (self.r * self.dual_scale) * dev.download("E"),
+                "mu": (self.r * self.dual_scale) * self._download("mu"),
+                "E": (self.r * self.dual_scale) * self._download("E"),
                 "iteration": it, "time": hist.get_running_time(), "kkt": np.array(org, dtype=object),
             })
             cps.pop(0)
@@ -325,7 +336,7 @@ class AlmSolver:
         dev, hist, validator = self.dev, self.run_history, self.kkt_validator
         validator.validator.validate(list(range(7)))
         org, _ = validator.collect()
-        cost, lagr = dev.objective()
+        cost, lagr = self._objective()
         hist.record(current_it=self.counter_main, kkt_errors=org,
                     history={"Transportation cost": cost, "Objective value": lagr})
         hist.end()
@@ -337,7 +348,7 @@ class AlmSolver:
             logger.warning("PCG hit its iteration cap in %d solves", self.cg_fail)
         solution = {}
         if download:
-            solution = {name: self.recovered(name, dev.download(name)) for name in STATE_NAMES}
+            solution = {name: self.recovered(name, self._download(name)) for name in STATE_NAMES}
         solution["checkpoints"] = self.checkpoint_solutions if self.checkpoint_solutions else None
         logger.info("Number of iterations: %d   Iteration time: %.2f", self.counter_main, hist.running_time)
         return solution, hist

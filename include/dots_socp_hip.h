@@ -17,6 +17,10 @@
  *       B, E                         (T+1, F, 3)
  *       z_mid, beta_mid              (T, 2, 3, F, 3)
  *     the device layout (vertex/triangle-major, time fastest) is internal.
+ *     A time-slab context (multi-GPU, dots_problem_desc.slab_*) exchanges its OWN time extent only:
+ *       phi (n, V); interval arrays (m, V); B, E (n, F, 3) with n = slab_count nodes, m = min(n, T - slab_begin)
+ *       intervals; z_mid, beta_mid (n, 2, 3, F, 3) indexed by the NODE an entry is compared with: entry [j][s] is the
+ *       reference's [slab_begin + j - s][s] (entries whose interval does not exist: ignored on upload, zero on download).
  *   - no C++ exceptions, torch types or Python objects cross this boundary.
  */
 #ifndef DOTS_SOCP_HIP_H
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DOTS_ABI_VERSION 1
+#define DOTS_ABI_VERSION 2
 
 typedef struct dots_ctx dots_ctx;
 
@@ -94,12 +98,13 @@ typedef struct dots_problem_desc {
     const double *time_modes;    /* [(T+1)*(T+1)] row-major Q[t][a]: orthonormal eigenvectors of the Neumann
                                     time Laplacian (laplacian_inverse_socp.py:15-31); NULL unless MODAL */
     const double *time_eigs;     /* [T+1] eigenvalues sigma_a >= 0 of -L_time;  NULL unless MODAL */
-    /* Multi-GPU (one context per rank): the time modes [mode_begin, mode_begin + mode_count) are solved
-     * by this context; mode_stride = modes per rank (ceil((T+1)/n_ranks), the same on every rank).
-     * All zero = single GPU, every mode.  See dots_step_begin / dots_step_end. */
-    int32_t mode_begin;
-    int32_t mode_count;
-    int32_t mode_stride;
+    /* Multi-GPU (one context per rank): TIME SLABS.  This context holds the time nodes [slab_begin, slab_begin +
+     * slab_count) of every state array (and the intervals that start at them) and solves the time modes with the same
+     * indices; slab_stride = nodes per rank (ceil((T+1)/n_ranks), the same on every rank; slab_count may be smaller, or
+     * 0, on trailing ranks).  All zero = single GPU.  See dots_slab_stage. */
+    int32_t slab_begin;
+    int32_t slab_count;
+    int32_t slab_stride;
     int32_t reserved;
 } dots_problem_desc;
 
@@ -157,7 +162,7 @@ int64_t dots_array_count(dots_ctx *ctx, int array_id);
  * meant for the direct solver, which needs no host round trip) -- any later call that returns data waits. */
 int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
 
-/* Flags for the following dots_step / dots_step_end calls.
+/* Flags for the following dots_step / dots_slab_stage calls.
  * DOTS_STEP_SKIP_Z_MID: z_mid (18*T*F values, an intermediate between the cone projection and steps 2+3) is
  * rebuilt on the fly and not stored: the iterate is the same bit for bit, but z_mid in memory is unspecified
  * afterwards.  dots_kkt(PRIM_Z) and dots_download(Z_MID) then fail with DOTS_ERR_STATE until a step without the
@@ -168,26 +173,50 @@ int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
  * solver_socp.py:668-672: A, B, lambda_c from the current multipliers, the stored z_mid and grad(phi) of the previous
  * iteration).  It reads z_mid from memory, so it cannot be combined with DOTS_STEP_SKIP_Z_MID (DOTS_ERR_ARGUMENT). */
 #define DOTS_STEP_PALM 2u
-int dots_step_flags(dots_ctx *ctx, uint32_t flags);
+int dots_step_flags(dots_ctx *ctx, uint32_t flags);      /* also apply to dots_slab_stage */
 
-/* One ALM iteration split around the only exchange of the multi-GPU path (mode-sharded solve):
- *   dots_step_begin  right-hand side + solve (direct sweeps or PCG) for this context's time modes; the mode-space solution
- *                    [V][pitch] (dots_shard_elems doubles) is copied to the DEVICE buffer `send`
- *   (caller)         all-gather of `send` over the ranks into `recv` = [n_ranks][V][pitch]  (RCCL)
- *   dots_step_end    inverse time transform from `recv`, then the cone projection and the
- *                    (q, lambda) + multiplier update
- * With stats != NULL both calls are synchronous with respect to the host (the context's stream is drained on
- * return), so the caller may hand the buffers to another stream/library.  With stats == NULL they only enqueue
- * on the context's stream; the caller orders the exchange against it with dots_stream_wait (no host wait at all:
- * begin, wait(other <- ctx), all-gather on `other`, wait(ctx <- other), end).  Every rank holds the complete ALM
- * state (the element-wise steps are replicated, the solve is not): results are bit-identical on all ranks. */
-int dots_step_begin(dots_ctx *ctx, double *send, int64_t count, dots_step_stats *stats);
-int dots_step_end(dots_ctx *ctx, const double *recv, int64_t count, dots_step_stats *stats);
+/* ---- time slabs (multi-GPU): one ALM iteration in four stages around three exchanges --------------------------------
+ * Every operator of the iteration is local in time except nearest-neighbour couplings (solver_socp.py:884, :892-894,
+ * :934-940, :955-957), and the Laplacian solve decouples over the time MODES (laplacian_inverse_socp.py:31-41).  Rank r
+ * holds the slab of nodes [r s, (r+1) s) of the whole state (s = slab_stride) and solves the modes [r s, (r+1) s):
+ *
+ *   stage 0   [is_palm: the (q, lambda_c) closed form]; pack what the neighbours need:
+ *               send_x   [V]  (A + lambda_c - mu) of this slab's last interval          -> next rank's  recv_x
+ *               send_nsq [V]  the s = 1 half of the cone norms of the interval that ends at this slab's first node
+ *                             (formed from this slab's B and beta_mid)                    -> previous rank's recv_nsq
+ *   (caller)  neighbour exchange (two V-sized messages per slab boundary)
+ *   stage 1   right-hand side of this slab's nodes + cone projection of its intervals; b_send = [V][pitch] right-hand
+ *             side followed by [V] cone multipliers of the slab's last interval
+ *   (caller)  all-gather of b_send into b_recv = [n_ranks][V * pitch + V]
+ *   stage 2   forward time transform restricted to this rank's modes, solve (sweeps or PCG); x_send = [V][pitch] solution
+ *   (caller)  all-gather of x_send into x_recv = [n_ranks][V * pitch]
+ *   stage 3   inverse time transform for this slab's nodes (+ the next slab's first node, computed redundantly),
+ *             steps 2 and 3
+ *   stage 4   (only before KKT residuals are evaluated) pack send_mu [V] (mu of the last interval -> next rank) and
+ *             send_b [3F] (B of the first node -> previous rank); the caller exchanges them, then dots_kkt_sums
+ *
+ * Stages must be called in order 0,1,2,3 (DOTS_ERR_STATE otherwise).  With stats == NULL a stage is only enqueued on the
+ * context's stream: the caller orders its exchanges against it with dots_stream_wait (no host wait anywhere).
+ * All buffers are DEVICE memory owned by the caller (e.g. torch tensors handed to RCCL), registered once with
+ * dots_slab_set_buffers; sizes from dots_slab_elems.  Results are bit-identical for every number of ranks, 1 included
+ * (the same sums are formed in the same order wherever a value is computed); only the KKT / objective sums differ in
+ * rounding (partial sums per slab). */
+typedef struct dots_slab_buffers {
+    double *send_x, *send_nsq;      /* [V] each: stage 0 output                                              */
+    double *recv_x, *recv_nsq;      /* [V] each: from the previous / next rank                               */
+    double *b_send, *b_recv;        /* [V * pitch + V], [n_ranks][V * pitch + V]                             */
+    double *x_send, *x_recv;        /* [V * pitch],     [n_ranks][V * pitch]                                 */
+    double *send_mu, *send_b;       /* [V], [3F]: stage 4 output                                             */
+    double *recv_mu, *recv_b;       /* [V], [3F]: from the previous / next rank                              */
+} dots_slab_buffers;
+enum dots_slab_size { DOTS_SLAB_VERTEX_HALO = 0, DOTS_SLAB_B_CHUNK = 1, DOTS_SLAB_X_CHUNK = 2, DOTS_SLAB_TRIANGLE_HALO = 3 };
+int64_t dots_slab_elems(dots_ctx *ctx, int which);      /* doubles; -1 if the context is not a time slab */
+int dots_slab_set_buffers(dots_ctx *ctx, const dots_slab_buffers *buffers);
+int dots_slab_stage(dots_ctx *ctx, int stage, dots_step_stats *stats);
 /* Stream ordering between the context's stream and another HIP stream of the same device (e.g. the one a
  * communication library works on; NULL = the legacy default stream).  ctx_waits = 0: work enqueued on
  * `other_stream` after the call waits for everything enqueued on the context so far; 1: the reverse. */
 int dots_stream_wait(dots_ctx *ctx, void *other_stream, int ctx_waits);
-int64_t dots_shard_elems(dots_ctx *ctx);   /* doubles one rank contributes: V * pitch;  -1 if not sharded */
 
 /* single phases of one iteration, for per-function parity tests */
 enum dots_phase {
@@ -203,10 +232,18 @@ int dots_run_phase(dots_ctx *ctx, int phase, dots_step_stats *stats);
  * (with prim/dual scale, with scale 1); entries of conditions not in mask are left untouched.
  * For conditions 4..6 the second value does not exist in the reference and is set to NaN. */
 int dots_kkt(dots_ctx *ctx, uint32_t mask, double *out /* [2*DOTS_N_KKT] */);
+/* The same in two halves, for time slabs: the weighted sums of this context's slab (DOTS_KKT_N_SUMS doubles; on a slab
+ * the halos of stage 4 must have been exchanged), and the residuals from the sums of the WHOLE problem (the caller adds
+ * the slabs' sums: one all-reduce of a small vector, solver_socp.py:433-559). */
+#define DOTS_KKT_N_SUMS 24
+int dots_kkt_sums(dots_ctx *ctx, uint32_t mask, double *sums /* [DOTS_KKT_N_SUMS] */);
+int dots_kkt_combine(dots_ctx *ctx, uint32_t mask, const double *sums, double *out /* [2*DOTS_N_KKT] */);
 
 /* objective_functional (solver_socp.py:417-431) as called at :773-775/:829-831:
  * out[0] = transportation cost, out[1] = Lagrangian / objective value. */
 int dots_objective(dots_ctx *ctx, double *out /* [2] */);
+int dots_objective_sums(dots_ctx *ctx, double *sums /* [3] */);
+int dots_objective_combine(dots_ctx *ctx, const double *sums /* [3] */, double *out /* [2] */);
 
 /* scaling tools (solver_socp.py:367-395).  These update the arrays only; the caller keeps
  * r / scale_z / const_d in dots_params consistent (dots_set_params). */
@@ -290,7 +327,7 @@ int dots_mg_enable(dots_ctx *ctx, int on);   /* switch between multigrid (1) and
 typedef struct dots_front_desc {
     int32_t n_nodes;
     int32_t n_levels;
-    int32_t n_modes;             /* modes the factor is given for (= T+1 on one GPU, mode_count when sharded) */
+    int32_t n_modes;             /* modes the factor is given for (= T+1 on one GPU, slab_count on a time slab) */
     int32_t pitch;               /* doubles per entry of values; must equal the context's mode pitch */
     int64_t n_front_rows;        /* length of front_idx, pull0, pull1 */
     int64_t n_entries;           /* rows of values = sum over nodes of (n+b)*n */

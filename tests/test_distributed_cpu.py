@@ -1,7 +1,8 @@
-"""CPU test of the N > 1 path: two processes, torch.distributed with the gloo backend, the real sharded
-driver (``ShardedAlmSolver`` + ``TorchComm``) on top of the numpy stand-in of the device API
-(tests/fake_device.py).  Checks the mode partition, the layout of the all-gathered buffer, that both ranks
-take identical decisions, and that the result equals the reference's recorded run."""
+"""CPU test of the N > 1 path: two / three processes, torch.distributed with the gloo backend, the real sharded
+driver (``ShardedAlmSolver`` + ``TorchComm``: stage order, neighbour exchanges, the two all-gathers, the all-reduced KKT
+sums) on top of the numpy stand-in of a time-slab device context (tests/fake_device.py), which checks every payload it
+receives against what the neighbour must hold.  Checks the slab partition, that all ranks take identical decisions,
+and that the result equals the reference's recorded run."""
 import os
 import socket
 import sys
@@ -25,7 +26,7 @@ def _worker(rank, world, port, fname, out_dir):
             sys.path.insert(0, p)
     import torch.distributed as dist
 
-    from dots_socp_amd.distributed import TorchComm, solver_socp_sharded
+    from dots_socp_amd.distributed import ShardedAlmSolver, TorchComm
     from fake_device import FakeDeviceProblem
 
     # the driver under test stays the product's own; only the device API underneath is the CPU stand-in
@@ -38,23 +39,32 @@ def _worker(rank, world, port, fname, out_dir):
         kw = {k[3:]: (g[k].tolist() if g[k].ndim else g[k].item()) for k in g.files if k.startswith("kw_")}
         comm = TorchComm()
         assert comm.size == world and comm.backend == "gloo"
-        sol, hist = solver_socp_sharded(int(g["n_time"]), geom, comm=comm, buffer_device="cpu", **kw)
+        nit = kw.pop("nit")
+        alm = ShardedAlmSolver(int(g["n_time"]), geom, comm=comm, buffer_device="cpu", nit=nit, **kw)
+        for _ in range(nit):
+            if alm.iterate():
+                break
+        sol, hist = alm.finalize()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), kkt=hist.kkt_errors, it=hist.kkt_iteration,
-                 cost=hist.history["Transportation cost"], mu=sol["mu"])
+                 cost=hist.history["Transportation cost"], mu=sol["mu"], beta_mid=sol["beta_mid"],
+                 checked=np.array([alm.dev.checked[k] for k in sorted(alm.dev.checked)]),
+                 calls=np.array([comm.calls[k] for k in sorted(comm.calls)]), iterations=np.array(alm.counter_main + 1))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fname", ["run_refplane4_T8_tol1e-3.npz", "run_torus_T5_cong_k15_steps.npz"])
-def test_two_rank_gloo_run_matches_reference(fname, tmp_path):
+@pytest.mark.parametrize("fname,world", [("run_refplane4_T8_tol1e-3.npz", 2), ("run_torus_T5_cong_k15_steps.npz", 3),
+                                         ("run_ico1_T6_palm_k12_steps.npz", 2)])
+def test_gloo_run_matches_reference(fname, world, tmp_path):
     import torch.multiprocessing as mp
 
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), fname, str(tmp_path)), nprocs=world, join=True)
     g = np.load(os.path.join(GOLDEN_DIR, fname))
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for k in ("kkt", "it", "cost", "mu"):
-        assert np.array_equal(r0[k], r1[k], equal_nan=True), f"ranks disagree on {k}"
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    r0 = ranks[0]
+    for r in ranks[1:]:
+        for k in ("kkt", "it", "cost", "mu", "beta_mid"):
+            assert np.array_equal(r0[k], r[k], equal_nan=True), f"ranks disagree on {k}"
     want = g["hist_kkt_errors"]
     assert int(r0["it"][-1]) == int(g["last_iteration"])
     assert np.array_equal(np.isnan(r0["kkt"]), np.isnan(want))
@@ -62,10 +72,24 @@ def test_two_rank_gloo_run_matches_reference(fname, tmp_path):
     assert np.allclose(r0["kkt"][m], want[m], rtol=1e-6, atol=1e-13)
     assert np.allclose(r0["cost"], g["hist_Transportation_cost"], rtol=1e-6, equal_nan=True)
     assert np.max(np.abs(r0["mu"] - g["sol_mu"])) < 1e-6 * np.max(np.abs(g["sol_mu"]))
+    assert np.max(np.abs(r0["beta_mid"] - g["sol_beta_mid"])) < 1e-6 * np.max(np.abs(g["sol_beta_mid"]))   # assembled from the slabs
+    # the wiring was exercised: every received payload was checked on the ranks that have the neighbour
+    n_it = int(r0["iterations"])
+    names = sorted(["recv_x", "recv_nsq", "lamc_lo", "b", "x", "recv_mu", "recv_b"])
+    for rank, r in enumerate(ranks):
+        checked = dict(zip(names, r["checked"].tolist()))
+        calls = dict(zip(sorted(["all_gather", "exchange", "all_reduce", "flag"]), r["calls"].tolist()))
+        assert checked["b"] == checked["x"] == n_it and calls["all_gather"] == 2 * n_it
+        assert checked["recv_x"] == (n_it if rank > 0 else 0) and checked["lamc_lo"] == (n_it if rank > 0 else 0)
+        assert checked["recv_nsq"] == (n_it if rank + 1 < world else 0)
+        assert (checked["recv_mu"] > 0) == (rank > 0) and (checked["recv_b"] > 0) == (rank + 1 < world)
+        assert calls["all_reduce"] > 0
 
 
-def test_mode_partition():
-    from dots_socp_amd.distributed import mode_partition
+def test_slab_partition():
+    from dots_socp_amd.distributed import mode_partition, slab_partition
+
+    assert mode_partition is slab_partition
 
     assert mode_partition(32, 8) == (4, [(4 * r, 4) for r in range(8)])
     assert mode_partition(32, 1) == (32, [(0, 32)])

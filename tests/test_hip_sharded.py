@@ -1,6 +1,6 @@
-"""GPU tests of the multi-GPU path on ONE device: the ranks are separate device contexts (separate
-time-mode ranges) driven by threads of this process, exchanging through ``ThreadComm``.  The sharded
-solve must reproduce the single-context solver (and therefore the reference) decision for decision."""
+"""GPU tests of the multi-GPU path on ONE device: the ranks are separate device contexts (time slabs of the state,
+time-mode ranges of the solve) driven by threads of this process, exchanging through ``ThreadComm``.  The sharded
+solve must reproduce the single-context solver bit for bit (and therefore the reference decision for decision)."""
 import os
 import threading
 
@@ -49,12 +49,87 @@ def run_ranks(n_ranks, fn):
     return out
 
 
-@pytest.mark.parametrize("direct", [False, True])
-@pytest.mark.parametrize("n_ranks", [2, 3, 4])
-def test_sharded_laplacian_equals_single_context(n_ranks, direct):
-    """One ALM iteration through begin / gather / end on n_ranks contexts == dots_step on one context."""
-    import torch
+class SlabGroup:
+    """n time-slab contexts on one GPU driven from ONE thread: the exchanges are plain tensor copies."""
 
+    def __init__(self, T, geom, n_ranks, **kw):
+        import torch
+
+        from dots_socp_amd.device import DeviceProblem
+
+        self.torch, self.n = torch, n_ranks
+        self.devs = [DeviceProblem(T, geom, lap_solver="modal_pcg", time_slab=(r, n_ranks), **kw) for r in range(n_ranks)]
+        self.bufs = []
+        for d in self.devs:
+            nv, nf, nb, nx = (d.slab_elems(k) for k in ("vertex_halo", "triangle_halo", "b_chunk", "x_chunk"))
+            z = lambda n: torch.zeros(n, dtype=torch.float64, device="cuda")       # noqa: E731
+            b = {"send_x": z(nv), "send_nsq": z(nv), "recv_x": z(nv), "recv_nsq": z(nv), "b_send": z(nb), "b_recv": z(nb * n_ranks),
+                 "x_send": z(nx), "x_recv": z(nx * n_ranks), "send_mu": z(nv), "send_b": z(nf), "recv_mu": z(nv), "recv_b": z(nf)}
+            d.slab_set_buffers(**{k: t.data_ptr() for k, t in b.items()})
+            self.bufs.append(b)
+        self.active = self.devs[0].active_ranks
+
+    def each(self, fn):
+        return [fn(d) for d in self.devs]
+
+    def upload(self, state):
+        for d in self.devs:
+            if d.nl:
+                for k, v in state.items():
+                    d.upload(k, d.to_slab(k, v))
+
+    def neighbours(self, fwd, bwd):
+        for d in self.devs:
+            d.sync()
+        for r in range(self.active):
+            if r > 0:
+                self.bufs[r][fwd[1]].copy_(self.bufs[r - 1][fwd[0]])
+            if r + 1 < self.active:
+                self.bufs[r][bwd[1]].copy_(self.bufs[r + 1][bwd[0]])
+        self.torch.cuda.synchronize()
+
+    def gather(self, send, recv):
+        for d in self.devs:
+            d.sync()
+        allv = self.torch.cat([b[send] for b in self.bufs])
+        for b in self.bufs:
+            b[recv].copy_(allv)
+        self.torch.cuda.synchronize()
+
+    def iterate(self):
+        self.each(lambda d: d.slab_stage(0))
+        self.neighbours(("send_x", "recv_x"), ("send_nsq", "recv_nsq"))
+        self.each(lambda d: d.slab_stage(1))
+        self.gather("b_send", "b_recv")
+        self.each(lambda d: d.slab_stage(2))
+        self.gather("x_send", "x_recv")
+        self.each(lambda d: d.slab_stage(3))
+
+    def kkt(self, conditions):
+        self.each(lambda d: d.slab_stage(4))
+        self.neighbours(("send_mu", "recv_mu"), ("send_b", "recv_b"))
+        total = sum(d.kkt_sums(conditions) for d in self.devs)
+        return self.devs[0].kkt_combine(conditions, total)
+
+    def objective(self):
+        return self.devs[0].objective_combine(sum(d.objective_sums() for d in self.devs))
+
+    def download(self, name):
+        full = np.zeros(self.devs[0].full_shape(name))
+        for d in self.devs:
+            if d.nl:
+                d.from_slab(name, d.download(name), full)
+        return full
+
+    def close(self):
+        self.each(lambda d: d.close())
+
+
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("n_ranks", [2, 3, 4, 6])
+def test_slab_iterations_equal_the_single_context(n_ranks, direct):
+    """Two ALM iterations + KKT residuals + objective on n time slabs == the same on one context (bit for bit with the
+    direct solver: every value is formed by the same sum in the same order; the PCG only to its tolerance)."""
     from dots_socp_amd.device import DeviceProblem
 
     g = golden("ops_torus8x6.npz")
@@ -63,46 +138,77 @@ def test_sharded_laplacian_equals_single_context(n_ranks, direct):
     rng = np.random.default_rng(3)
     state = {k: rng.standard_normal(getattr(s, k).shape) for k in O.OracleSolver.STATE}
     single = DeviceProblem(T, geom, lap_solver="modal_pcg")
-    devs = [DeviceProblem(T, geom, lap_solver="modal_pcg", mode_shard=(r, n_ranks)) for r in range(n_ranks)]
-    for d in [single] + devs:
-        for k, v in state.items():
-            d.upload(k, v)
-        d.set_params(r=1.3, scale_z=2.0, const_d=2.0, cg_tol=1e-12)
-        if direct:
+    group = SlabGroup(T, geom, n_ranks)
+    for k, v in state.items():
+        single.upload(k, v)
+    group.upload(state)
+    params = dict(r=1.3, scale_z=2.0, const_d=2.0, congestion=0.07, cg_tol=1e-13)
+    for d in [single] + group.devs:
+        d.set_params(**params)
+        if direct and d.nl:
             d.setup_frontal(leaf=4)
-    single.step(1)
-    elems = devs[0].shard_elems()
-    sends = [torch.zeros(elems, dtype=torch.float64, device="cuda") for _ in devs]
-    for d, snd in zip(devs, sends):
-        d.step_begin(snd.data_ptr(), elems)
-    recv = torch.cat(sends)
-    for d in devs:
-        d.step_end(recv.data_ptr(), recv.numel())
-    want = single.download_all()
-    for d in devs:
-        got = d.download_all()
-        for k in want:
-            scale = max(np.max(np.abs(want[k])), 1e-300)
-            assert np.max(np.abs(got[k] - want[k])) < 1e-9 * scale, k
-    # replicated state is bit-identical across ranks
-    a, b = devs[0].download_all(), devs[-1].download_all()
-    assert all(np.array_equal(a[k], b[k]) for k in a)
-    for d in [single] + devs:
-        d.close()
+    for _ in range(2):
+        single.step(1)
+        group.iterate()
+    tol = 0.0 if direct else 1e-9
+    for k in state:
+        want, got = single.download(k), group.download(k)
+        scale = max(np.max(np.abs(want)), 1e-300)
+        assert np.max(np.abs(got - want)) <= tol * scale, k
+    conds = list(range(7))
+    want, got = single.kkt(conds), group.kkt(conds)
+    for i in conds:
+        assert got[i][0] == pytest.approx(want[i][0], rel=1e-12 if direct else 1e-7)
+    assert group.objective() == pytest.approx(single.objective(), rel=1e-12 if direct else 1e-7)
+    # per-rank device memory: the state is divided, not replicated
+    state_bytes = sum(np.prod(single.shape(k)) for k in state) * 8
+    stride = -(-(T + 1) // n_ranks)
+    pitch = max(4, 1 << (stride - 1).bit_length())
+    full_pitch = max(8, 1 << T.bit_length())
+    for d in group.devs:
+        assert d.device_bytes() < single.device_bytes() * (pitch / full_pitch) * 1.35 + 2e6, (d.device_bytes(), single.device_bytes(), state_bytes)
+    single.close()
+    group.close()
+
+
+def test_slab_stage_order_and_stale_halos_are_errors():
+    from dots_socp_amd import _lib
+
+    g = golden("ops_ico1.npz")
+    group = SlabGroup(int(g["n_time"]), geom_of(g), 2)
+    d = group.devs[0]
+    with pytest.raises(_lib.HipLibraryError, match="order"):
+        d.slab_stage(2)
+    with pytest.raises(_lib.HipLibraryError, match="slab"):
+        d.step(1)
+    with pytest.raises(_lib.HipLibraryError, match="slab"):
+        d.kkt([0])
+    group.iterate()
+    with pytest.raises(_lib.HipLibraryError, match="stale"):
+        d.kkt_sums([2])
+    d.kkt_sums([0, 1, 3, 6])      # conditions without a time stencil across the slab boundary need no halo
+    group.close()
 
 
 @pytest.mark.parametrize("fname,n_ranks,mg", [
     ("run_ico2_T15_cong_tol1e-3.npz", 2, "mg"),
     ("run_ico2_T15_cong_tol1e-3.npz", 4, "jacobi"),
     ("run_ico2_T15_cong_tol1e-3.npz", 3, "direct"),
+    ("run_ico2_T15_cong_tol1e-3.npz", 8, "direct"),
+    ("run_ico2_T15_palm_tol1e-3.npz", 4, "direct"),
+    ("run_ico2_T15_ckpt_tol1e-3.npz", 2, "direct"),
     ("run_torus_T7_tol1e-4.npz", 3, "mg"),
     ("run_torus_T7_tol1e-4.npz", 2, "direct"),
+    ("run_torus_T5_eps_k15_steps.npz", 3, "direct"),
     ("run_refplane4_T8_tol1e-3.npz", 2, "jacobi"),
     ("run_refplane4_T8_tol1e-3.npz", 4, "direct"),
+    ("run_ico1_T6_k150_lazy.npz", 7, "direct"),
 ])
 def test_sharded_runs_match_reference(fname, n_ranks, mg):
-    """Whole solves on n_ranks 'GPUs': every rank stops at the reference's iteration with its cost and KKT."""
+    """Whole solves on n_ranks 'GPUs': every rank stops at the reference's iteration with its cost and KKT, and holds
+    the same answer as the single-GPU solver (bit for bit with the direct solver)."""
     from dots_socp_amd.distributed import solver_socp_sharded
+    from dots_socp_amd.socp import solver_socp
 
     g = golden(fname)
     kw = {k[3:]: (g[k].tolist() if g[k].ndim else g[k].item()) for k in g.files if k.startswith("kw_")}
@@ -112,7 +218,7 @@ def test_sharded_runs_match_reference(fname, n_ranks, mg):
         kw.update(lap_solver="modal_pcg", cg_tol=1e-11, preconditioner="multigrid" if mg == "mg" else "jacobi", mg_coarsest=6)
 
     def rank_main(comm):
-        return solver_socp_sharded(int(g["n_time"]), geom_of(g), comm=comm, device=0, **kw)
+        return solver_socp_sharded(int(g["n_time"]), geom_of(g), comm=comm, device=0, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
 
     results = run_ranks(n_ranks, rank_main)
     want = g["hist_kkt_errors"]
@@ -123,22 +229,83 @@ def test_sharded_runs_match_reference(fname, n_ranks, mg):
         assert np.allclose(hist.kkt_errors[m], want[m], rtol=1e-6, atol=1e-13)
         assert np.allclose(hist.history["Transportation cost"], g["hist_Transportation_cost"], rtol=1e-6, equal_nan=True)
         assert np.max(np.abs(sol["mu"] - g["sol_mu"])) < 1e-5 * np.max(np.abs(g["sol_mu"]))
-    # all ranks hold the same answer bit for bit
+        if "ckpt_iteration" in g.files:
+            assert [c["iteration"] for c in sol["checkpoints"]] == g["ckpt_iteration"].tolist()
+            assert np.max(np.abs(np.stack([c["mu"] for c in sol["checkpoints"]]) - g["ckpt_mu"])) < 1e-5 * np.max(np.abs(g["ckpt_mu"]))
+    # all ranks hold the same answer bit for bit ...
     for sol, _ in results[1:]:
-        assert np.array_equal(sol["mu"], results[0][0]["mu"])
+        for k in ("mu", "E", "phi", "beta_mid"):
+            assert np.array_equal(sol[k], results[0][0][k]), k
+    if mg == "direct":      # ... and it is the single-GPU solver's
+        one, _ = solver_socp(int(g["n_time"]), geom_of(g), **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+        for k in ("mu", "E", "phi", "A", "B", "z_fst", "beta_mid", "beta_end"):
+            assert np.array_equal(one[k], results[0][0][k]), k
 
 
-def test_more_ranks_than_modes():
-    """T+1 = 5 modes on 8 ranks: three ranks own no mode and still take part in the exchange."""
+def test_more_ranks_than_nodes():
+    """T+1 = 5 nodes on 8 ranks: three ranks hold no node / mode and still take part in the collectives."""
     from dots_socp_amd import meshes
-    from dots_socp_amd.distributed import mode_partition, solver_socp_sharded
+    from dots_socp_amd.distributed import slab_partition, solver_socp_sharded
     from dots_socp_amd.socp import solver_socp
 
     geom, _ = meshes.example("sphere", level=1)
-    stride, parts = mode_partition(5, 8)
+    stride, parts = slab_partition(5, 8)
     assert stride == 1 and [c for _, c in parts] == [1, 1, 1, 1, 1, 0, 0, 0]
     ref_sol, ref_hist = solver_socp(4, geom, nit=25, tol=1e-12)
     results = run_ranks(8, lambda comm: solver_socp_sharded(4, geom, comm=comm, nit=25, tol=1e-12))
     for sol, hist in results:
-        assert np.allclose(hist.history["Transportation cost"], ref_hist.history["Transportation cost"], rtol=1e-8, equal_nan=True)
-        assert np.max(np.abs(sol["mu"] - ref_sol["mu"])) < 1e-7 * np.max(np.abs(ref_sol["mu"]))
+        assert np.allclose(hist.history["Transportation cost"], ref_hist.history["Transportation cost"], rtol=1e-12, equal_nan=True)
+        assert np.array_equal(sol["mu"], ref_sol["mu"])
+
+
+@pytest.mark.parametrize("T,n_ranks", [(127, 4), (63, 3)])
+def test_slabs_at_long_time_axes(T, n_ranks):
+    """T + 1 = 128 / 64: the tiled transforms of a slab context stage Q in chunks (time pitch >= 128) -- same iterates as
+    one context, which runs the matrix-core transforms there."""
+    from dots_socp_amd import meshes
+    from dots_socp_amd.distributed import solver_socp_sharded
+    from dots_socp_amd.socp import solver_socp
+
+    geom, _ = meshes.example("sphere", level=2)
+    kw = dict(nit=12, tol=1e-12, congestion=0.02)
+    one, one_hist = solver_socp(T, geom, **kw)
+    results = run_ranks(n_ranks, lambda comm: solver_socp_sharded(T, geom, comm=comm, **kw))
+    for sol, hist in results:
+        assert np.allclose(hist.history["Transportation cost"], one_hist.history["Transportation cost"], rtol=1e-9, equal_nan=True)
+        for k in ("mu", "phi", "B"):
+            assert np.max(np.abs(sol[k] - one[k])) <= 1e-9 * np.max(np.abs(one[k])), k
+
+
+def test_finite_time_limit_adds_no_collectives_to_quiet_iterations():
+    """The wall-clock decision is shared only on iterations that read back anyway: between them an
+    iteration costs exactly one neighbour exchange and two all-gathers, whatever time_limit is."""
+    from dots_socp_amd import meshes
+    from dots_socp_amd.distributed import ShardedAlmSolver
+
+    geom, _ = meshes.example("sphere", level=1)
+
+    def rank_main(comm):
+        alm = ShardedAlmSolver(6, geom, comm=comm, nit=400, tol=1e-30, time_limit=1000)
+        for _ in range(150):
+            alm.iterate()
+        quiet = alm.untimed_steps
+        calls = dict(comm.calls)
+        clock = alm.clock_exchanges
+        alm.close()
+        return quiet, calls, clock
+
+    for quiet, calls, clock in run_ranks(2, rank_main):
+        assert quiet > 90                                   # most iterations only enqueue
+        assert calls["all_gather"] == 2 * 150
+        assert calls["flag"] == clock == 150 - quiet        # one clock exchange per iteration that reads back
+        assert calls["exchange"] >= 150 and calls["exchange"] <= 150 + (150 - quiet)
+
+
+def test_time_limit_stops_every_rank_on_the_same_iteration():
+    from dots_socp_amd import meshes
+    from dots_socp_amd.distributed import solver_socp_sharded
+
+    geom, _ = meshes.example("sphere", level=2)
+    results = run_ranks(3, lambda comm: solver_socp_sharded(15, geom, comm=comm, nit=100000, tol=1e-30, time_limit=0.3))
+    its = [int(h.kkt_iteration[-1]) for _, h in results]
+    assert len(set(its)) == 1 and 5 < its[0] < 100000
