@@ -1,6 +1,7 @@
 """GPU tests of the multi-GPU path on ONE device: the ranks are separate device contexts (time slabs of the state,
 time-mode ranges of the solve) driven by threads of this process, exchanging through ``ThreadComm``.  The sharded
-solve must reproduce the single-context solver bit for bit (and therefore the reference decision for decision)."""
+solve must reproduce the single-context solver to rounding (and therefore the reference decision for decision) and be
+bit-identical across its ranks."""
 import os
 import threading
 
@@ -128,8 +129,9 @@ class SlabGroup:
 @pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("n_ranks", [2, 3, 4, 6])
 def test_slab_iterations_equal_the_single_context(n_ranks, direct):
-    """Two ALM iterations + KKT residuals + objective on n time slabs == the same on one context (bit for bit with the
-    direct solver: every value is formed by the same sum in the same order; the PCG only to its tolerance)."""
+    """Two ALM iterations + KKT residuals + objective on n time slabs == the same on one context, to rounding: the
+    element-wise steps form the same sums in the same order, the sweeps split their dot products by the mode pitch (which
+    is smaller on a slab), the PCG stops at its tolerance (and fixes the free constant of phi differently)."""
     from dots_socp_amd.device import DeviceProblem
 
     g = golden("ops_torus8x6.npz")
@@ -150,16 +152,19 @@ def test_slab_iterations_equal_the_single_context(n_ranks, direct):
     for _ in range(2):
         single.step(1)
         group.iterate()
-    tol = 0.0 if direct else 1e-9
+    tol = 1e-12 if direct else 1e-8
+    mass = O.OracleSolver(T, geom).mass_v[None, :]
     for k in state:
         want, got = single.download(k), group.download(k)
+        if k == "phi":       # eps = 0: phi is defined up to a constant
+            want, got = want - np.sum(want * mass) / (np.sum(mass) * (T + 1)), got - np.sum(got * mass) / (np.sum(mass) * (T + 1))
         scale = max(np.max(np.abs(want)), 1e-300)
         assert np.max(np.abs(got - want)) <= tol * scale, k
     conds = list(range(7))
     want, got = single.kkt(conds), group.kkt(conds)
     for i in conds:
-        assert got[i][0] == pytest.approx(want[i][0], rel=1e-12 if direct else 1e-7)
-    assert group.objective() == pytest.approx(single.objective(), rel=1e-12 if direct else 1e-7)
+        assert got[i][0] == pytest.approx(want[i][0], rel=1e-10 if direct else 1e-7)
+    assert group.objective() == pytest.approx(single.objective(), rel=1e-10 if direct else 1e-7)
     # per-rank device memory: the state is divided, not replicated
     state_bytes = sum(np.prod(single.shape(k)) for k in state) * 8
     stride = -(-(T + 1) // n_ranks)
@@ -205,8 +210,8 @@ def test_slab_stage_order_and_stale_halos_are_errors():
     ("run_ico1_T6_k150_lazy.npz", 7, "direct"),
 ])
 def test_sharded_runs_match_reference(fname, n_ranks, mg):
-    """Whole solves on n_ranks 'GPUs': every rank stops at the reference's iteration with its cost and KKT, and holds
-    the same answer as the single-GPU solver (bit for bit with the direct solver)."""
+    """Whole solves on n_ranks 'GPUs': every rank stops at the reference's iteration with its cost and KKT, all ranks
+    hold the same answer bit for bit, and it is the single-GPU solver's to rounding."""
     from dots_socp_amd.distributed import solver_socp_sharded
     from dots_socp_amd.socp import solver_socp
 
@@ -236,10 +241,11 @@ def test_sharded_runs_match_reference(fname, n_ranks, mg):
     for sol, _ in results[1:]:
         for k in ("mu", "E", "phi", "beta_mid"):
             assert np.array_equal(sol[k], results[0][0][k]), k
-    if mg == "direct":      # ... and it is the single-GPU solver's
-        one, _ = solver_socp(int(g["n_time"]), geom_of(g), **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
-        for k in ("mu", "E", "phi", "A", "B", "z_fst", "beta_mid", "beta_end"):
-            assert np.array_equal(one[k], results[0][0][k]), k
+    if mg == "direct":      # ... and it is the single-GPU solver's (the sweeps round differently: their dot products are split by the mode pitch)
+        one, one_hist = solver_socp(int(g["n_time"]), geom_of(g), **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+        assert int(one_hist.kkt_iteration[-1]) == int(results[0][1].kkt_iteration[-1])
+        for k in ("mu", "E", "A", "B", "z_fst", "beta_mid", "beta_end"):
+            assert np.max(np.abs(one[k] - results[0][0][k])) <= 1e-8 * np.max(np.abs(one[k])), k
 
 
 def test_more_ranks_than_nodes():
@@ -254,8 +260,8 @@ def test_more_ranks_than_nodes():
     ref_sol, ref_hist = solver_socp(4, geom, nit=25, tol=1e-12)
     results = run_ranks(8, lambda comm: solver_socp_sharded(4, geom, comm=comm, nit=25, tol=1e-12))
     for sol, hist in results:
-        assert np.allclose(hist.history["Transportation cost"], ref_hist.history["Transportation cost"], rtol=1e-12, equal_nan=True)
-        assert np.array_equal(sol["mu"], ref_sol["mu"])
+        assert np.allclose(hist.history["Transportation cost"], ref_hist.history["Transportation cost"], rtol=1e-11, equal_nan=True)
+        assert np.max(np.abs(sol["mu"] - ref_sol["mu"])) < 1e-10 * np.max(np.abs(ref_sol["mu"]))
 
 
 @pytest.mark.parametrize("T,n_ranks", [(127, 4), (63, 3)])
