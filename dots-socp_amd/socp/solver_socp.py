@@ -114,7 +114,8 @@ class AlmSolver:
         if is_constant_scaling:
             self._initial_constant_scaling(init_solution)                # :574-586
 
-        conditions = [ErrorCondition((lambda i=i: self._kkt([i])[i]), tol, KKT_SHORT_LABELS[i]) for i in range(7)]
+        self._kkt_cache = {}
+        conditions = [ErrorCondition((lambda i=i: self._kkt_value(i)), tol, KKT_SHORT_LABELS[i]) for i in range(7)]
         self.kkt_validator = AdaptiveValidator(ConditionValidator(conditions, KKT_QUEUE_ORDER))   # :589-645
         self.start_time = time.perf_counter()
 
@@ -152,12 +153,14 @@ class AlmSolver:
 
     # ---- scaling tools (solver_socp.py:324-412) -------------------------------------------
     def adjust_penalty(self, factor):
+        self._kkt_cache = {}
         self.r *= factor
         self.dev.adjust_penalty(factor)
         self._push()
 
     def scale_variable_z(self, scale_factor, msg="Scale z"):
         logger.log(12, "%s with z factor: %s", msg, scale_factor)
+        self._kkt_cache = {}
         self.scale_z *= scale_factor
         self.const_d *= scale_factor
         self.norm_d *= scale_factor
@@ -166,6 +169,7 @@ class AlmSolver:
         self._push()
 
     def scale_prim_dual(self, scale_factor=None):
+        self._kkt_cache = {}
         dev = self.dev
         if scale_factor is None:
             n2 = dev.norm_square
@@ -226,6 +230,19 @@ class AlmSolver:
             return (self.r * self.dual_scale) * arr
         return (self.r * self.scale_z * self.dual_scale) * arr
 
+    # ---- KKT residuals of the current iterate, evaluated at most once each: the conditions an iteration is known to need
+    # (the four primal / dual ones before a penalty update, all seven in step-by-step mode and at the end) are fetched in
+    # ONE device call (one pass of the KKT kernels, one host round trip) instead of one call per condition
+    def _kkt_value(self, i):
+        if i not in self._kkt_cache:
+            self._kkt_cache.update(self._kkt([i]))
+        return self._kkt_cache[i]
+
+    def _kkt_prefetch(self, conditions):
+        missing = [i for i in conditions if i not in self._kkt_cache]
+        if missing:
+            self._kkt_cache.update(self._kkt(missing))
+
     # ---- what the multi-GPU solver overrides: everything that reads numbers or arrays back from the device(s)
     def _kkt(self, conditions):
         return self.dev.kkt(conditions)
@@ -283,6 +300,7 @@ class AlmSolver:
                       or (self.is_constant_scaling and params.is_to_scale(it + 1)))   # the next iteration opens with norms of z
         is_time_used_up = self._time_is_up(reads_back)
         quiet = not (is_time_used_up or reads_back)
+        self._kkt_cache = {}
         self._device_step(quiet)                                                # steps 1-3 (:674-722)
 
         adjust = params.is_to_adjust(it) or is_time_used_up
@@ -292,6 +310,7 @@ class AlmSolver:
         if not self.check_kkt_step_by_step:
             if adjust:
                 validator.reset_counter()
+                self._kkt_prefetch(required)
             passed, _info = validator.validate(required)
             org, scaled = validator.collect()
             if adjust:
@@ -301,6 +320,7 @@ class AlmSolver:
             if error is not None:
                 validator.set_error_and_tolerance(error, self.tol)
         else:
+            self._kkt_prefetch(range(7))
             passed, _info = validator.validator.validate(list(range(7)))
             org, scaled = validator.collect()
             cost, lagr = self._objective()
@@ -334,6 +354,7 @@ class AlmSolver:
     # ---- final record and solution (:826-871) ------------------------------------------------
     def finalize(self, download=True):
         dev, hist, validator = self.dev, self.run_history, self.kkt_validator
+        self._kkt_prefetch(range(7))
         validator.validator.validate(list(range(7)))
         org, _ = validator.collect()
         cost, lagr = self._objective()
