@@ -29,7 +29,7 @@ EXPORTS = [
     "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
     "dots_slab_elems", "dots_slab_set_buffers", "dots_slab_stage", "dots_kkt_sums", "dots_kkt_combine", "dots_objective_sums",
-    "dots_objective_combine", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
+    "dots_objective_combine", "dots_front_launches", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
     "dots_symbolic_build", "dots_symbolic_front_rows", "dots_symbolic_copy", "dots_symbolic_free",
 ]
 
@@ -171,6 +171,7 @@ def load():
     lib.dots_front_setup.argtypes = [vp, C.POINTER(FrontDesc)]
     lib.dots_front_enable.argtypes = [vp, C.c_int]
     lib.dots_front_pitch.argtypes = [vp]
+    lib.dots_front_launches.argtypes = [vp]
     lib.dots_step_flags.argtypes = [vp, C.c_uint32]
     lib.dots_stream_wait.argtypes = [vp, vp, C.c_int]
     i64p = C.POINTER(C.c_int64)

@@ -197,7 +197,8 @@ static int build(Ctx *c, const dots_problem_desc *p) {
             if ((rc = dev_alloc(c, q, nnode))) return rc;
     }
     const int gv = xcd_grid(d.n_vtiles), gf = xcd_grid(d.n_ftiles);
-    const int64_t npart = std::max<int64_t>({(int64_t)MAX_SUMS * std::max(gv, gf) * 2, cg_partials_needed(d), 4096});
+    // KKT kernels: one workgroup per quarter tile, N_VSUMS + N_FSUMS <= MAX_SUMS slots each
+    const int64_t npart = std::max<int64_t>({(int64_t)MAX_SUMS * std::max(gv, gf) * (TILE_ELEMS / BLOCK) * 2, cg_partials_needed(d), 4096});
     if ((rc = dev_alloc(c, &d.partials, npart))) return rc;
     if ((rc = dev_alloc(c, &d.scal, CgScalOffsets::TOTAL))) return rc;
     if ((rc = dev_alloc(c, &d.flags, FLAG_TOTAL))) return rc;
@@ -830,6 +831,11 @@ int dots_front_enable(dots_ctx *c, int on) {
     if (on && c->front.n_nodes == 0) { set_error("front_enable: no factor installed"); return DOTS_ERR_STATE; }
     c->use_front = on ? 1 : 0;
     return 0;
+}
+
+int dots_front_launches(dots_ctx *c) {
+    if (check(c) || c->front.n_nodes == 0) return -1;
+    return 2 * c->front.n_levels;
 }
 
 int dots_front_pitch(dots_ctx *c) {

@@ -244,7 +244,7 @@ struct Ctx {
     int front_vec2 = 1;           // two modes per lane in the sweeps (DOTS_FRONT_VEC2: 0 never, 1 where bandwidth-bound, 2 always)
     int front_rb_max = 4;         // most rows (columns) of a node per workgroup (DOTS_FRONT_RB: 1, 2 or 4, for A/B measurements)
     double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps)
-    void *front_allocs[24]{};
+    void *front_allocs[48]{};
     int n_front_allocs = 0;
     void *mg_allocs[160]{};
     int n_mg_allocs = 0;
@@ -262,6 +262,25 @@ struct Ctx {
         return t[id];
     }
 };
+
+// device copy of a host array owned by the factor (released by front_release)
+template <typename T>
+inline int front_upload(Ctx *c, const T **out, const T *host, int64_t count) {
+    void *p = nullptr;
+    const size_t bytes = sizeof(T) * (size_t)(count > 1 ? count : 1);
+    DOTS_HIP(hipMalloc(&p, bytes));
+    if (c->n_front_allocs >= (int)(sizeof(c->front_allocs) / sizeof(c->front_allocs[0]))) {
+        (void)hipFree(p);
+        set_error("front allocation table full");
+        return DOTS_ERR_STATE;
+    }
+    c->front_allocs[c->n_front_allocs++] = p;
+    if (host) DOTS_HIP(hipMemcpyAsync(p, host, sizeof(T) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    else DOTS_HIP(hipMemsetAsync(p, 0, bytes, c->stream));
+    DOTS_HIP(hipStreamSynchronize(c->stream));
+    *out = (const T *)p;
+    return 0;
+}
 
 // The time-mode transforms stage a tile of rows and Q (in chunks of <= 32 KB) in LDS (k_time_modes_tile, k_rhs_modes)
 // T + 1 >= 64: the transforms are [V x (T+1)] x [(T+1) x (T+1)] fp64 GEMMs worth the matrix cores (k_time_modes_mfma)

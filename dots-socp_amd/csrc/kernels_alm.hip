@@ -477,12 +477,31 @@ int launch_scale_array(Ctx *c, int id, double f) {
     return 0;
 }
 
-int launch_adjust_penalty(Ctx *c, double factor) {  // :367-371 (the boundary term is rebuilt from r in k_rhs)
-    const int ids[5] = {DOTS_MU, DOTS_E, DOTS_BETA_FST, DOTS_BETA_MID, DOTS_BETA_END};
-    for (int id : ids) {
-        const int64_t n = array_count_device(c->d, id);
-        hipLaunchKernelGGL(k_divide, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, c->arr(id), n, factor);
+// x /= f for the five dual arrays in ONE launch (same division as k_divide, element for element)
+struct DivideFive {
+    double *p[5];
+    int64_t end[5];      // running element counts
+};
+__global__ __launch_bounds__(BLOCK) void k_divide_five(DivideFive a, double f) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.end[4]; i += (int64_t)gridDim.x * BLOCK) {
+        int k = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k += i >= a.end[q];
+        const int64_t j = i - (k ? a.end[k - 1] : 0);
+        a.p[k][j] /= f;
     }
+}
+
+int launch_adjust_penalty(Ctx *c, double factor) {  // :367-371 (the boundary term is rebuilt from r in k_rhs)
+    const int ids[5] = {DOTS_BETA_MID, DOTS_E, DOTS_MU, DOTS_BETA_FST, DOTS_BETA_END};
+    DivideFive a{};
+    int64_t n = 0;
+    for (int k = 0; k < 5; ++k) {
+        a.p[k] = c->arr(ids[k]);
+        n += array_count_device(c->d, ids[k]);
+        a.end[k] = n;
+    }
+    hipLaunchKernelGGL(k_divide_five, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, a, factor);
     DOTS_HIP(hipGetLastError());
     return 0;
 }

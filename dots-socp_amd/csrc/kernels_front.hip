@@ -249,24 +249,6 @@ void front_release(Ctx *c) {
     c->front_bytes = 0.0;
 }
 
-template <typename T>
-static int front_upload(Ctx *c, const T **out, const T *host, int64_t count) {
-    void *p = nullptr;
-    const size_t bytes = sizeof(T) * (size_t)std::max<int64_t>(count, 1);
-    DOTS_HIP(hipMalloc(&p, bytes));
-    if (c->n_front_allocs >= (int)(sizeof(c->front_allocs) / sizeof(c->front_allocs[0]))) {
-        (void)hipFree(p);
-        set_error("front allocation table full");
-        return DOTS_ERR_STATE;
-    }
-    c->front_allocs[c->n_front_allocs++] = p;
-    if (host) DOTS_HIP(hipMemcpyAsync(p, host, sizeof(T) * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    else DOTS_HIP(hipMemsetAsync(p, 0, bytes, c->stream));
-    DOTS_HIP(hipStreamSynchronize(c->stream));
-    *out = (const T *)p;
-    return 0;
-}
-
 int front_setup(Ctx *c, const dots_front_desc *h) {
     const Dev &d = c->dcg;
     auto bad = [&](const char *what) {

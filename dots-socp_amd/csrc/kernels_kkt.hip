@@ -26,16 +26,21 @@ struct KktArgs {
     double r, sz, cd, cong, ps, ds, bs;   // penalty, scale_factor_z, constant_d, congestion, prim/dual/boundary scale
 };
 
+// One element per thread (a workgroup takes a quarter of a tile, as the cone projection does): the corner walks of
+// Comp(rho, f(q)) and Dual(alpha) are chains of dependent loads, and these kernels run on the iterations whose
+// residuals the host waits for.
 __global__ __launch_bounds__(BLOCK) void k_kkt_vertex(Dev d, KktArgs a) {
     __shared__ double lds[N_VSUMS * 4];
-    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    constexpr int SUB = TILE_ELEMS / BLOCK;
+    const int G8 = gridDim.x / SUB;
+    const int tile = xcd_tile(blockIdx.x % G8, d.n_vtiles);
     double s[N_VSUMS];
 #pragma unroll
     for (int i = 0; i < N_VSUMS; ++i) s[i] = 0.0;
     const bool c0 = a.mask & 1u, c1 = a.mask & 2u, c2 = a.mask & 4u, c3 = a.mask & 8u, c4 = a.mask & 16u, c6 = a.mask & 64u;
     if (tile < d.n_vtiles) {
         const double ih = 1.0 / d.h, rho_s = a.ds * a.r;
-        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        for (int e = (blockIdx.x / G8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
             const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
             if (v >= d.V || t >= d.nl) continue;
             const int iv = idxV(d, v, t);
@@ -113,14 +118,16 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_vertex(Dev d, KktArgs a) {
 
 __global__ __launch_bounds__(BLOCK) void k_kkt_triangle(Dev d, KktArgs a, double *part) {
     __shared__ double lds[N_FSUMS * 4];
-    const int tile = xcd_tile(blockIdx.x, d.n_ftiles);
+    constexpr int SUB = TILE_ELEMS / BLOCK;
+    const int G8 = gridDim.x / SUB;
+    const int tile = xcd_tile(blockIdx.x % G8, d.n_ftiles);
     double s[N_FSUMS];
 #pragma unroll
     for (int i = 0; i < N_FSUMS; ++i) s[i] = 0.0;
     const bool c0 = a.mask & 1u, c1 = a.mask & 2u, c3 = a.mask & 8u, c5 = a.mask & 32u;
     if (tile < d.n_ftiles) {
         const double sB = a.sz * INV_SQRT3, rho_s = a.ds * a.r;
-        for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        for (int e = (blockIdx.x / G8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
             const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
             if (row >= 3 * d.F || t >= d.nl) continue;
             const int f = row / 3, c = row - 3 * f;
@@ -216,7 +223,7 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
     const Dev &d = c->d;
     const dots_params &p = c->prm;
     KktArgs a{mask, p.r, p.scale_z, p.const_d, p.congestion, p.prim_scale, p.dual_scale, p.boundary_scale};
-    const int gv = xcd_grid(d.n_vtiles), gf = xcd_grid(d.n_ftiles);
+    const int gv = xcd_grid(d.n_vtiles) * (TILE_ELEMS / BLOCK), gf = xcd_grid(d.n_ftiles) * (TILE_ELEMS / BLOCK);
     double *part_f = d.partials + (int64_t)N_VSUMS * gv;
     const bool need_v = mask & (1u | 2u | 4u | 8u | 16u | 64u), need_f = mask & (1u | 2u | 8u | 32u);
     for (int i = 0; i < N_SUMS; ++i) sums[i] = 0.0;

@@ -387,7 +387,11 @@ class DeviceProblem:
         d.level_ptr, d.level_nodes, d.values = _ptr(keep[9], C.c_int32), _ptr(keep[10], C.c_int32), _ptr(keep[11], C.c_double)
         _lib.check(self.lib.dots_front_setup(self._h, C.byref(d)), "dots_front_setup")
         self.front_summary = dict(ff.stats)
+        self.front_summary["launches_per_solve"] = self.front_launches()
         return self.front_summary
+
+    def front_launches(self):
+        return int(self.lib.dots_front_launches(self._h))
 
     def enable_frontal(self, on=True):
         _lib.check(self.lib.dots_front_enable(self._h, 1 if on else 0), "dots_front_enable")

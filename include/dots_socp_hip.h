@@ -371,6 +371,8 @@ int64_t dots_symbolic_front_rows(const dots_symbolic *sym);
 int dots_symbolic_copy(const dots_symbolic *sym, int32_t *node_b, int32_t *front_idx, int32_t *pull0, int32_t *pull1);
 void dots_symbolic_free(dots_symbolic *sym);
 int dots_front_enable(dots_ctx *ctx, int on);
+/* launches one direct solve takes: 2 x tree height (one per height and sweep) */
+int dots_front_launches(dots_ctx *ctx);
 /* the mode pitch `values` must be laid out with (power of two >= the context's mode count, >= 8) */
 int dots_front_pitch(dots_ctx *ctx);
 
