@@ -106,6 +106,10 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     }
     d.TP = tp;
     d.tp_shift = sh;
+    if (((int64_t)d.V << sh) >= ((int64_t)1 << 31)) {      // node arrays are indexed with 32-bit arithmetic (idxV)
+        set_error("V * time pitch must stay below 2^31 per context: cut the time axis into more slabs");
+        return DOTS_ERR_ARGUMENT;
+    }
     d.VT = d.FT = TILE_ELEMS / tp;
     d.n_vtiles = (d.V + d.VT - 1) / d.VT;
     d.n_ftiles = (3 * d.F + d.FT - 1) / d.FT;
