@@ -210,6 +210,9 @@ def solve_roofline(alm, V, n_time):
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "ms_per_solve": ms_solve, "launches_per_solve": launches, "ms_per_launch": ms_solve / max(launches, 1),
             "algorithmic_bytes_per_solve": bytes_solve, "factor": fs,
+            "bytes_note": "achieved / frac use the algorithmic bytes of the solve: the factor with one block per tree node, twice, + 4 vector "
+                          "passes; the sweeps run on bands of merged tree heights (factor.bands) whose blocks hold more entries "
+                          "(factor.bytes_per_solve_as_installed): the extra bytes are the price of fewer dependent launches and are NOT counted",
         }, bytes_solve
     ms_apply, bytes_apply = alm.dev.bench_kernel(which=0, reps=200)
     ms_update, bytes_update = alm.dev.bench_kernel(which=1, reps=200)

@@ -10,7 +10,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libdotsocp_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ARRAY_IDS = {
     "phi": 0, "A": 1, "B": 2, "lambda_c": 3, "z_fst": 4, "z_mid": 5, "z_end": 6,
@@ -29,7 +29,7 @@ EXPORTS = [
     "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
     "dots_slab_elems", "dots_slab_set_buffers", "dots_slab_stage", "dots_kkt_sums", "dots_kkt_combine", "dots_objective_sums",
-    "dots_objective_combine", "dots_front_launches", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
+    "dots_objective_combine", "dots_front_launches", "dots_front_info", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
     "dots_symbolic_build", "dots_symbolic_front_rows", "dots_symbolic_copy", "dots_symbolic_free",
 ]
 
@@ -87,6 +87,7 @@ class FrontDesc(C.Structure):
         ("node_n", _i32p), ("node_b", _i32p), ("node_foff", C.POINTER(C.c_int64)), ("node_ioff", C.POINTER(C.c_int64)),
         ("node_uoff", C.POINTER(C.c_int64)), ("node_child", _i32p), ("front_idx", _i32p), ("pull0", _i32p), ("pull1", _i32p),
         ("level_ptr", _i32p), ("level_nodes", _i32p), ("values", _f64p), ("grounded", _i32p),
+        ("band_ptr", _i32p), ("n_bands", C.c_int32),
     ]
 
 
@@ -172,6 +173,7 @@ def load():
     lib.dots_front_enable.argtypes = [vp, C.c_int]
     lib.dots_front_pitch.argtypes = [vp]
     lib.dots_front_launches.argtypes = [vp]
+    lib.dots_front_info.argtypes = [vp, _f64p]
     lib.dots_step_flags.argtypes = [vp, C.c_uint32]
     lib.dots_stream_wait.argtypes = [vp, vp, C.c_int]
     i64p = C.POINTER(C.c_int64)

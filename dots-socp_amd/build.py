@@ -19,6 +19,7 @@ SOURCES = ["dots_api.hip", "kernels_alm.hip", "kernels_cg.hip", "kernels_mg.hip"
 HEADERS = [os.path.join(CSRC, "dots_dev.h"), os.path.join(PKG_DIR, "..", "include", "dots_socp_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+FLAGS += os.environ.get("DOTS_HIPCC_FLAGS", "").split()      # extra -D switches for A/B measurements of compile-time variants
 
 
 def hipcc() -> str:

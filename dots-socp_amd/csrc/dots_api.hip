@@ -842,6 +842,17 @@ int dots_front_launches(dots_ctx *c) {
     return 2 * c->front.n_levels;
 }
 
+int dots_front_info(dots_ctx *c, double *out) {
+    int rc = check(c);
+    if (rc) return rc;
+    if (!out || c->front.n_nodes == 0) { set_error("front_info: no factor installed"); return DOTS_ERR_STATE; }
+    out[0] = c->front_bytes_unmerged;
+    out[1] = c->front_bytes;
+    out[2] = (double)c->front_heights;
+    out[3] = (double)c->front.n_levels;
+    return 0;
+}
+
 int dots_front_pitch(dots_ctx *c) {
     if (check(c)) return -1;
     return c->dcg.TP;

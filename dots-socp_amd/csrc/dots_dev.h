@@ -128,22 +128,50 @@ struct FrontNode {
     int64_t ioff;             // first front row in the pull maps
     int64_t soff;             // first entry of the b x b Schur complement
 };
-// One workgroup of a sweep: the node's record and the first row (column) of its block, in ONE 96-byte record so
-// that the kernel's dependent-load chain starts with a single (scalar) load instead of descriptor -> node record.
+// One node of the SWEEPS (kernels_front.hip): an original node, or the nodes of a band of tree heights that hang together
+// merged into one block F' = [L'^-1 ; G'] (row stride n; L'^-1 block lower triangular over the members, children first).
+struct SweepNode {
+    int n, b;                 // columns = separator rows of all members / boundary rows (those of the band's top node)
+    int k0;                   // sweep-order index of the first separator row
+    int planes;               // update planes of this node that a child writes (the launch reads the band's bucket: 0, 2, 4 or 8)
+    int64_t foff;             // first (row, col) entry of F'
+    int64_t woff;             // first row of this node's update planes in W, m rows each
+    int64_t parent_w;         // first row of the plane this node writes in its parent's W (-1: root)
+    int64_t bdoff;            // first boundary row of this node in bd_vertex / cmap
+};
+// One workgroup of a sweep: the node's record and its block of rows (columns), in ONE 96-byte record so that the
+// kernel's dependent-load chain starts with a single (scalar) load instead of descriptor -> node record.
 struct FrontWork {
-    FrontNode nd;
-    int first;
+    SweepNode nd;
+    int first;                // first row (forward) / first column (backward) of the block
+    int lo;                   // forward: first column that can be nonzero in the block's rows; backward: number of row ranges
+    int rs[4], re[4];         // backward: separator-row ranges [rs, re) that can be nonzero in the block's columns (rs[0] = first)
+    int end;                  // backward: one past the last column of the block's member
+    int pad;
+};
+// One original node inside a merged band node (k_merge_member builds F' from the members' own blocks)
+struct MergeMember {
+    int n, b;                 // its separator / boundary rows
+    int o, c0;                // first own column / first column of its subtree inside the merged node
+    int64_t foff;             // its block [L^-1 ; G] in the factor (row stride n)
+    int64_t ioff;             // first front row in the pull maps
+    int64_t dst;              // first entry of the merged node's F'
+    int64_t uoff;             // first entry of U_s (the update operator of its subtree on its boundary; columns from c0)
+    int ns;                   // row stride of F' = columns of the merged node
+    int ustride;              // row stride of U_s
+    int uin;                  // U_s lives in: 0 the factor (its own G rows: no child inside the band), 1 scratch, 2 F' (the band's top node)
+    int ch[2];                // its children inside the band by pull map (index of the member record, -1: none or below the band)
     int pad;
 };
 struct FrontDev {
-    int n_nodes = 0, n_levels = 0;
-    const FrontNode *nodes = nullptr;
-    const int *vmap = nullptr;            // elimination index -> device vertex; nullptr when the device numbering is the elimination order
+    int n_nodes = 0, n_levels = 0;        // original nodes; launches per sweep (= bands of tree heights)
+    const FrontNode *nodes = nullptr;     // original tree (factorisation)
+    const int *vmap = nullptr;            // sweep-order index -> device vertex; nullptr when the device numbering is the sweep order
     const int *bd_vertex = nullptr;       // device vertex of every boundary row
     const int *cmap = nullptr;            // position of every boundary row in the parent's front
-    const double *F = nullptr;
+    const double *F = nullptr;            // original blocks, then the merged ones
     double *W = nullptr;                  // update planes [rows][TP]; entries no child writes stay zero
-    const FrontWork *fwd_desc = nullptr, *bwd_desc = nullptr;             // per workgroup: node record + first row / first column
+    const FrontWork *fwd_desc = nullptr, *bwd_desc = nullptr;             // per workgroup: node record + its block
 };
 
 // Layout of the device scalar block used by the PCG (all arrays have NC entries, NC <= 256).
@@ -241,9 +269,12 @@ struct Ctx {
     int front_fwd_ptr[66]{}, front_bwd_ptr[66]{};   // workgroup ranges of the tree levels in fwd_desc / bwd_desc
     int front_fwd_rb[65]{}, front_bwd_cb[65]{};     // rows / columns per workgroup on each level
     int front_fwd_nb[65]{}, front_bwd_nb[65]{};     // threads per workgroup on each level (256, or 1024 where a level has few rows)
+    int front_planes[65]{};       // update planes the forward launch of a band reads per node (0, 2, 4 or 8)
     int front_vec2 = 1;           // two modes per lane in the sweeps (DOTS_FRONT_VEC2: 0 never, 1 where bandwidth-bound, 2 always)
     int front_rb_max = 4;         // most rows (columns) of a node per workgroup (DOTS_FRONT_RB: 1, 2 or 4, for A/B measurements)
-    double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps)
+    double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps, merged blocks as stored)
+    double front_bytes_unmerged = 0.0;   // the same for one launch per tree height (no merged bands)
+    int front_heights = 0;        // tree heights of the installed factor
     void *front_allocs[48]{};
     int n_front_allocs = 0;
     void *mg_allocs[160]{};

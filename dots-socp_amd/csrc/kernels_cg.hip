@@ -836,7 +836,7 @@ int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes) {
         float tf = 0.f;
         DOTS_HIP(hipEventElapsedTime(&tf, c->ev[6], c->ev[7]));
         *ms = (double)tf / reps;
-        *bytes = c->front_bytes + 8.0 * (double)d.V * d.cg_ncol * 4.0;   // factor twice; b read, y written + read, x written
+        *bytes = c->front_bytes_unmerged + 8.0 * (double)d.V * d.cg_ncol * 4.0;   // factor twice (one block per tree node: merged bands read more, dots_front_info); b read, y written + read, x written
         return 0;
     }
     if (which == 2 && !a.mg) {

@@ -20,10 +20,29 @@
 // index the mode and folded by wave shuffles + LDS.
 // HBM-bound: one solve reads sum_p (n_p (n_p + 1) / 2 + b_p n_p) * modes * 8 bytes twice and touches the
 // vectors (V * modes * 8 bytes) a handful of times.
+//
+// MERGED HEIGHTS (dots_front_desc.band_ptr).  On small meshes a launch per tree height costs more than the bytes it
+// streams (4-5 us of dependent latencies for a few MB).  The nodes of a band of heights [lo, hi) that hang together
+// are therefore combined into ONE sweep node, algebraically and without a new factorisation (k_merge_member):
+//     member s, child c inside the band:  L'^-1[rows of s, columns of c's subtree] = -L_s^-1 U_c[rows of sep_s]
+//                                         U_s[columns of c's subtree]              = U_c[rows of bd_s] - G_s U_c[rows of sep_s]
+//     own columns:                        L_s^-1 and U_s = G_s;       G' = U of the band's top node
+// F' = [L'^-1 ; G'] has the shape the sweeps expect (the blocks of unrelated members stay zero and are never read:
+// the forward rows carry their first column, the backward columns their row ranges), the nodes below the band write
+// their updates into planes of the merged node (nodes whose boundaries do not meet share a plane), and a solve takes
+// 2 x (number of bands) launches.  numpy restatement: tests/frontal_cpu.py (merge, solve_merged).
 #include "dots_dev.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
 #include <vector>
+
+#ifndef DOTS_FRONT_UNROLL
+#define DOTS_FRONT_UNROLL 1
+#endif
 
 namespace dots {
 
@@ -101,17 +120,18 @@ __device__ __forceinline__ Vd<1> front_folded_wide(const double *red, int r, int
     return s;
 }
 
-// forward sweep of one tree height.  Workgroup = (node, rb <= RB rows); thread = (VEC modes from a, part q of the dot
-// product).  Every load of the loop body is unconditional (rows past the block are clamped to its first row and
-// their sums dropped; leaves read their "children's" planes from the zero pad at the start of W; the upper triangle
-// of L^-1 is stored as zeros), so that the compiler issues the RB + 3 loads of a step back to back and waits once.
-// RB is the level's exact block size (1, 2 or 4: no duplicate loads); LEAF (tree height 0): no update planes to read.
-template <int NB, int RB, bool VMAP, bool LEAF, int VEC>
+// forward sweep of one band of tree heights.  Workgroup = (node, rb <= RB rows); thread = (VEC modes from a, part q of
+// the dot product).  Every load of the loop body is unconditional (rows past the block are clamped to its first row
+// and their sums dropped; planes no child writes hold zeros; the upper triangle of L^-1 is stored as zeros), so that
+// the compiler issues the RB + 1 + KP loads of a step back to back and waits once.
+// RB is the band's exact block size (1, 2 or 4: no duplicate loads); KP the update planes the band's nodes read
+// (0 on the bottom band: leaves only).
+template <int NB, int RB, bool VMAP, int KP, int VEC>
 __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const FrontWork *__restrict__ desc, int rb, const double *__restrict__ bhat,
                                                   double *__restrict__ Y) {
     __shared__ double red[RB * (NB / 64) * 64 * VEC];
     const FrontWork wk = desc[blockIdx.x];
-    const FrontNode &nd = wk.nd;
+    const SweepNode &nd = wk.nd;
     const int row0 = wk.first;
     const int sh = g.sh, tid = threadIdx.x;
     const int shv = VEC == 2 ? sh - 1 : sh;                      // log2 of the lanes per row part
@@ -119,7 +139,7 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
     const bool wide = (g.TP / VEC) > 64;                         // only with VEC == 1
     const int n = nd.n, m = n + nd.b;
     const double *__restrict__ Fp = f.F + (nd.foff << sh) + a;
-    const double *__restrict__ W0 = f.W + (nd.woff << sh) + a;         // child 0's plane; child 1's is m rows further
+    const double *__restrict__ W0 = f.W + (nd.woff << sh) + a;         // plane 0; plane k is k * m rows further
     const int64_t plane = (int64_t)m << sh;
     const bool live = a < g.ncol;
     const int nr = min(rb, m - row0);
@@ -133,28 +153,54 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
         rowp[r] = Fp + (((int64_t)(r < nr ? row0 + r : row0) * n) << sh);
     }
     // where this thread's (first) update row goes in the parent's plane: loaded now, needed after the fold
-    const int cm0 = (q < nr && row0 + q >= n) ? f.cmap[nd.bdoff + (row0 + q - n)] : 0;
-    // rows of L^-1 only need the columns j <= i: the block's last row bounds the loop
+    const bool upd0 = q < nr && row0 + q >= n;
+    const int cm0 = upd0 ? f.cmap[nd.bdoff + (row0 + q - n)] : 0;
+    Vd<VEC> cp0[KP > 0 ? KP : 1];      // ... and what the children carried to that row
+    if (KP > 0 && upd0 && live) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) cp0[k] = vload<VEC>(W0 + k * plane + ((int64_t)(row0 + q) << sh));
+    }
+    // rows of L^-1 only need the columns j <= i: the block's last row bounds the loop; wk.lo: the first column of the
+    // block's rows that is not in a zero block of the merged node
     const int last = row0 + nr - 1;
     const int jmax = last < n ? last + 1 : n;
+    // U steps of the dot product are loaded before the first is used (merged nodes have long rows: a step per
+    // memory round trip would leave the workgroup waiting on latency)
+    constexpr int U = !DOTS_FRONT_UNROLL ? 1 : ((1 + KP + RB) * VEC <= 6) ? 4 : (((1 + KP + RB) * VEC <= 12) ? 2 : 1);
     if (live) {
-        for (int j = q; j < jmax; j += Q) {
-            const int64_t jo = (int64_t)j << sh;
-            const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
-            const Vd<VEC> wb = vload<VEC>(bhat + (row << sh) + a);
-            Vd<VEC> w0, w1, fv[RB];
-            if (!LEAF) {
-                w0 = vload<VEC>(W0 + jo);
-                w1 = vload<VEC>(W0 + plane + jo);
+        for (int j0 = wk.lo + q; j0 < jmax; j0 += U * Q) {
+            Vd<VEC> wb[U], wp[U][KP > 0 ? KP : 1], fv[U][RB];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * Q;
+                ok[u] = u == 0 || j < jmax;
+                if (ok[u]) {
+                    const int64_t jo = (int64_t)j << sh;
+                    const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
+                    wb[u] = vload<VEC>(bhat + (row << sh) + a);
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) wp[u][k] = vload<VEC>(W0 + k * plane + jo);
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) fv[u][r] = vload<VEC>(rowp[r] + jo);
+                }
             }
 #pragma unroll
-            for (int r = 0; r < RB; ++r) fv[r] = vload<VEC>(rowp[r] + jo);
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) {
-                const double w = LEAF ? wb.v[c] : wb.v[c] - (w0.v[c] + w1.v[c]);
+                for (int c = 0; c < VEC; ++c) {
+                    double w = wb[u].v[c];
+                    if (KP > 0) {
+                        double t = wp[u][0].v[c];
 #pragma unroll
-                for (int r = 0; r < RB; ++r) acc[r].v[c] += fv[r].v[c] * w;
-            }
+                        for (int k = 1; k < KP; ++k) t += wp[u][k].v[c];
+                        w -= t;
+                    }
+                    if (ok[u]) {
+#pragma unroll
+                        for (int r = 0; r < RB; ++r) acc[r].v[c] += fv[u][r].v[c] * w;
+                    }
+                }
         }
     }
     if (VEC == 1 && wide) front_fold_wide<NB, RB>(reinterpret_cast<Vd<1>(&)[RB]>(acc), red, tid);
@@ -167,10 +213,17 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
         if (i < n) {
             vstore<VEC>(Y + (front_row(f, nd.k0 + i) << sh) + a, s);
         } else {   // update row: carry the children's contributions on, hand the sum to the parent's plane
-            if (!LEAF) {
-                const Vd<VEC> c0 = vload<VEC>(W0 + ((int64_t)i << sh)), c1 = vload<VEC>(W0 + plane + ((int64_t)i << sh));
+            if (KP > 0) {
+                Vd<VEC> cp[KP > 0 ? KP : 1];
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) s.v[c] += c0.v[c] + c1.v[c];
+                for (int k = 0; k < KP; ++k) cp[k] = r == q ? cp0[k] : vload<VEC>(W0 + k * plane + ((int64_t)i << sh));
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    double u = cp[0].v[c];
+#pragma unroll
+                    for (int k = 1; k < KP; ++k) u += cp[k].v[c];
+                    s.v[c] += u;
+                }
             }
             const int cm = r == q ? cm0 : f.cmap[nd.bdoff + (i - n)];
             vstore<VEC>(f.W + ((nd.parent_w + cm) << sh) + a, s);
@@ -178,13 +231,15 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
     }
 }
 
-// backward sweep of one tree height.  Workgroup = (node, cb <= RB columns).  Same load discipline.
+// backward sweep of one band.  Workgroup = (node, cb <= RB columns of ONE member of the node).  Same load discipline.
+// The rows that can be nonzero in these columns: the member's own rows from the block's first column on, the rows of
+// its ancestors inside the band (wk.rs / wk.re, wk.lo ranges), the boundary rows.
 template <int NB, int RB, bool VMAP, int VEC>
 __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const FrontWork *__restrict__ desc, int cb, const double *__restrict__ Y,
                                                   double *X) {
     __shared__ double red[RB * (NB / 64) * 64 * VEC];
     const FrontWork wk = desc[blockIdx.x];
-    const FrontNode &nd = wk.nd;
+    const SweepNode &nd = wk.nd;
     const int col0 = wk.first;
     const int sh = g.sh, tid = threadIdx.x;
     const int shv = VEC == 2 ? sh - 1 : sh;
@@ -194,7 +249,7 @@ __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const
     const double *__restrict__ Fp = f.F + (nd.foff << sh) + a;
     const int *__restrict__ bdv = f.bd_vertex + nd.bdoff;
     const bool live = a < g.ncol;
-    const int nc = min(cb, n - col0);
+    const int nc = min(cb, wk.end - col0);
 
     Vd<VEC> acc[RB];
     int64_t co[RB];      // column offsets (columns past the block: its first column, sums dropped)
@@ -204,31 +259,62 @@ __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const
         for (int c = 0; c < VEC; ++c) acc[r].v[c] = 0.0;
         co[r] = (int64_t)(r < nc ? col0 + r : col0) << sh;
     }
+    constexpr int U = !DOTS_FRONT_UNROLL ? 1 : ((1 + RB) * VEC <= 4) ? 4 : (((1 + RB) * VEC <= 10) ? 2 : 1);      // as in the forward sweep
     if (live) {
-        // rows of the separator: y_p.  Column i of L^-1 is zero above the diagonal: start at the block's first column
-        for (int j = col0 + q; j < n; j += Q) {
-            const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
-            const Vd<VEC> v = vload<VEC>(Y + (row << sh) + a);
-            const double *__restrict__ Fj = Fp + (((int64_t)j * n) << sh);
-            Vd<VEC> fv[RB];
+        // rows of the separators: y.  Column i of L^-1 is zero above the diagonal: start at the block's first column
 #pragma unroll
-            for (int r = 0; r < RB; ++r) fv[r] = vload<VEC>(Fj + co[r]);
+        for (int rg = 0; rg < 4; ++rg) {
+            if (rg < wk.lo) {
+                const int r1 = wk.re[rg];
+                for (int j0 = wk.rs[rg] + q; j0 < r1; j0 += U * Q) {
+                    Vd<VEC> v[U], fv[U][RB];
+                    bool ok[U];
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
+                    for (int u = 0; u < U; ++u) {
+                        const int j = j0 + u * Q;
+                        ok[u] = u == 0 || j < r1;
+                        if (ok[u]) {
+                            const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
+                            v[u] = vload<VEC>(Y + (row << sh) + a);
+                            const double *__restrict__ Fj = Fp + (((int64_t)j * n) << sh);
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) acc[r].v[c] += fv[r].v[c] * v.v[c];
+                            for (int r = 0; r < RB; ++r) fv[u][r] = vload<VEC>(Fj + co[r]);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (ok[u]) {
+#pragma unroll
+                            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                                for (int c = 0; c < VEC; ++c) acc[r].v[c] += fv[u][r].v[c] * v[u].v[c];
+                        }
+                }
+            }
         }
-        // boundary rows: -x of the ancestors (written by the launches of greater heights)
-        for (int j = n + q; j < m; j += Q) {
-            const Vd<VEC> v = vload<VEC>(X + ((int64_t)bdv[j - n] << sh) + a);
-            const double *__restrict__ Fj = Fp + (((int64_t)j * n) << sh);
-            Vd<VEC> fv[RB];
+        // boundary rows: -x of the ancestors (written by the launches of the bands above)
+        for (int j0 = n + q; j0 < m; j0 += U * Q) {
+            Vd<VEC> v[U], fv[U][RB];
+            bool ok[U];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) fv[r] = vload<VEC>(Fj + co[r]);
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * Q;
+                ok[u] = u == 0 || j < m;
+                if (ok[u]) {
+                    v[u] = vload<VEC>(X + ((int64_t)bdv[j - n] << sh) + a);
+                    const double *__restrict__ Fj = Fp + (((int64_t)j * n) << sh);
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
+                    for (int r = 0; r < RB; ++r) fv[u][r] = vload<VEC>(Fj + co[r]);
+                }
+            }
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) acc[r].v[c] -= fv[r].v[c] * v.v[c];
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) acc[r].v[c] -= fv[u][r].v[c] * v[u].v[c];
+                }
         }
     }
     if (VEC == 1 && wide) front_fold_wide<NB, RB>(reinterpret_cast<Vd<1>(&)[RB]>(acc), red, tid);
@@ -241,13 +327,129 @@ __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const
     }
 }
 
+// ---- merged bands: F' of a merged node from its members' blocks (see the header comment) ---------------------
+struct MergeArgs {
+    int sh, TP, ncol;
+    double *F;                  // original blocks, then the merged ones
+    double *scratch;            // U_s of the members that are neither at the bottom nor at the top of their band
+    const int *pull0, *pull1;   // front position -> row in the child's boundary, or -1
+    const MergeMember *mem;
+    const int *list;            // member records this launch handles (one tree height of one band)
+};
+
+// grid (blocks of entries, members).  A thread = (mode, entry (i, column) of [rows of s's front] x [columns of s's
+// subtree in the merged node]); the members' children inside the band were handled by the launches before.
+__global__ __launch_bounds__(256) void k_merge_member(MergeArgs g) {
+    const MergeMember s = g.mem[g.list[blockIdx.y]];
+    const int sh = g.sh, tid = threadIdx.x;
+    const int a = tid & (g.TP - 1), q = tid >> sh, Q = 256 >> sh;
+    if (a >= g.ncol) return;
+    const int n = s.n, m = n + s.b, w = s.o + n - s.c0;
+    const double *__restrict__ Fs = g.F + (s.foff << sh) + a;                 // entry (i, t): ((i * n + t) << sh)
+    double *__restrict__ Fd = g.F + (s.dst << sh) + a;                        // entry (row, col): ((row * ns + col) << sh)
+    double *__restrict__ Us = (s.uin == 1 ? g.scratch : g.F) + (s.uoff << sh) + a;
+    const int64_t total = (int64_t)m * w;
+    for (int64_t e = (int64_t)blockIdx.x * Q + q; e < total; e += (int64_t)gridDim.x * Q) {
+        const int i = (int)(e / w), jj = (int)(e % w), col = s.c0 + jj;
+        double val;
+        if (col >= s.o) {
+            if (i >= n && s.uin == 0) continue;           // its own G rows already are U_s
+            val = Fs[((int64_t)i * n + (col - s.o)) << sh];
+        } else {
+            int k = 0;
+            MergeMember c = g.mem[s.ch[0] >= 0 ? s.ch[0] : s.ch[1]];
+            if (s.ch[0] < 0 || col < c.c0 || col >= c.o + c.n) { k = 1; c = g.mem[s.ch[1]]; }
+            const int *__restrict__ pull = (k == 0 ? g.pull0 : g.pull1) + s.ioff;
+            const double *__restrict__ Uc = (c.uin == 1 ? g.scratch : g.F) + (c.uoff << sh) + a + ((int64_t)(col - c.c0) << sh);
+            const double *__restrict__ Fi = Fs + (((int64_t)i * n) << sh);
+            const int tmax = i < n ? i + 1 : n;
+            double acc = 0.0;
+            for (int t = 0; t < tmax; ++t) {
+                const int r = pull[t];
+                if (r >= 0) acc += Fi[(int64_t)t << sh] * Uc[((int64_t)r * c.ustride) << sh];
+            }
+            if (i < n) val = -acc;
+            else {
+                const int r = pull[i];
+                val = (r >= 0 ? Uc[((int64_t)r * c.ustride) << sh] : 0.0) - acc;
+            }
+        }
+        if (i < n) Fd[((int64_t)(s.o + i) * s.ns + col) << sh] = val;
+        else Us[((int64_t)(i - n) * s.ustride + jj) << sh] = val;
+    }
+}
+
+// two modes per lane (16-byte loads): pays where the sweeps are bandwidth-bound (measured: +6 % at torus100k, +13 % at
+// T = 127; -2 % on the latency-bound sphere10k, where it is left off)
+static bool front_two_modes(const Ctx *c) {
+    const Dev &d = c->dcg;
+    return c->front_vec2 && d.TP >= 4 && d.TP <= 128 && (c->front_vec2 > 1 || d.TP >= 64 || c->front_bytes > 1.0e9);
+}
+
+// one band of the forward sweep: n workgroups of nbt threads, blk rows each, kp update planes per node
+static void front_launch_fwd(Ctx *c, const FrontDev &f, const FrontWork *ptr, int n, int nbt, int blk, int kp, const double *bhat, double *y) {
+    const Dev &d = c->dcg;
+    const FrontArgs g{d.tp_shift, d.TP, d.cg_ncol};
+    const bool vm = f.vmap != nullptr, v2 = front_two_modes(c);
+#define FRONT_FWD4(NBV, RBV, KPV)                                                                                                  \
+    do {                                                                                                                           \
+        if (v2) {                                                                                                                  \
+            if (vm) hipLaunchKernelGGL((k_front_fwd<NBV, RBV, true, KPV, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);  \
+            else hipLaunchKernelGGL((k_front_fwd<NBV, RBV, false, KPV, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);    \
+        } else {                                                                                                                   \
+            if (vm) hipLaunchKernelGGL((k_front_fwd<NBV, RBV, true, KPV, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);  \
+            else hipLaunchKernelGGL((k_front_fwd<NBV, RBV, false, KPV, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);    \
+        }                                                                                                                          \
+    } while (0)
+#define FRONT_FWD(NBV, RBV)                                                                                                        \
+    do {                                                                                                                           \
+        if (kp == 0) FRONT_FWD4(NBV, RBV, 0);                                                                                      \
+        else if (kp == 2) FRONT_FWD4(NBV, RBV, 2);                                                                                 \
+        else if (kp == 4) FRONT_FWD4(NBV, RBV, 4);                                                                                 \
+        else FRONT_FWD4(NBV, RBV, 8);                                                                                              \
+    } while (0)
+    if (nbt == 1024) { if (blk == 1) FRONT_FWD(1024, 1); else if (blk == 2) FRONT_FWD(1024, 2); else FRONT_FWD(1024, 4); }
+    else { if (blk == 1) FRONT_FWD(256, 1); else if (blk == 2) FRONT_FWD(256, 2); else FRONT_FWD(256, 4); }
+#undef FRONT_FWD
+#undef FRONT_FWD4
+}
+
+static void front_launch_bwd(Ctx *c, const FrontDev &f, const FrontWork *ptr, int n, int nbt, int blk, const double *y, double *x) {
+    const Dev &d = c->dcg;
+    const FrontArgs g{d.tp_shift, d.TP, d.cg_ncol};
+    const bool vm = f.vmap != nullptr, v2 = front_two_modes(c);
+#define FRONT_BWD(NBV, RBV)                                                                                                        \
+    do {                                                                                                                           \
+        if (v2) {                                                                                                                  \
+            if (vm) hipLaunchKernelGGL((k_front_bwd<NBV, RBV, true, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);  \
+            else hipLaunchKernelGGL((k_front_bwd<NBV, RBV, false, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);    \
+        } else {                                                                                                                   \
+            if (vm) hipLaunchKernelGGL((k_front_bwd<NBV, RBV, true, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);  \
+            else hipLaunchKernelGGL((k_front_bwd<NBV, RBV, false, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);    \
+        }                                                                                                                          \
+    } while (0)
+    if (nbt == 1024) { if (blk == 1) FRONT_BWD(1024, 1); else if (blk == 2) FRONT_BWD(1024, 2); else FRONT_BWD(1024, 4); }
+    else { if (blk == 1) FRONT_BWD(256, 1); else if (blk == 2) FRONT_BWD(256, 2); else FRONT_BWD(256, 4); }
+#undef FRONT_BWD
+}
+
 void front_release(Ctx *c) {
     for (int i = 0; i < c->n_front_allocs; ++i) (void)hipFree(c->front_allocs[i]);
     c->n_front_allocs = 0;
     c->front = FrontDev{};
     c->use_front = 0;
-    c->front_bytes = 0.0;
+    c->front_bytes = c->front_bytes_unmerged = 0.0;
+    c->front_heights = 0;
 }
+
+namespace {
+struct Group {                 // one node of the sweeps
+    int root = -1, band = 0;
+    std::vector<int> members;  // original nodes, ascending = children first
+    int n = 0, b = 0, k0 = 0, planes = 0, colour = -1, parent = -1;
+    int64_t foff = 0, woff = 0;
+};
+}  // namespace
 
 int front_setup(Ctx *c, const dots_front_desc *h) {
     const Dev &d = c->dcg;
@@ -263,7 +465,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     // ---- index sanity: a wrong index would fault on the device -------------------------------------
     const int nn = h->n_nodes;
     int64_t fo = 0, io = 0, uo = 0, eliminated = 0;
-    double entries_read = 0.0;
+    double entries_unmerged = 0.0;
     for (int p = 0; p < nn; ++p) {
         const int64_t n = h->node_n[p], b = h->node_b[p];
         if (n < 0 || b < 0 || n + b < 1) return bad("node size");
@@ -284,11 +486,11 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         io += n + b;
         uo += b;
         eliminated += n;
-        entries_read += 0.5 * n * (n + 1) + (double)b * n;
+        entries_unmerged += 0.5 * n * (n + 1) + (double)b * n;
     }
     if (fo != h->n_entries || io != h->n_front_rows || uo != h->update_rows || eliminated != d.V) return bad("totals do not match");
     if (h->level_ptr[0] != 0 || h->level_ptr[h->n_levels] != nn) return bad("level_ptr");
-    std::vector<int> level_of(nn, -1);
+    std::vector<int> level_of(nn, -1), parent(nn, -1);
     for (int l = 0; l < h->n_levels; ++l) {
         if (h->level_ptr[l + 1] < h->level_ptr[l]) return bad("level_ptr not monotone");
         for (int k = h->level_ptr[l]; k < h->level_ptr[l + 1]; ++k) {
@@ -300,24 +502,34 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     for (int p = 0; p < nn; ++p)
         for (int k = 0; k < 2; ++k) {
             const int ch = h->node_child[2 * p + k];
-            if (ch >= 0 && level_of[ch] >= level_of[p]) return bad("a child is not on a lower level than its parent");
+            if (ch < 0) continue;
+            if (level_of[ch] >= level_of[p]) return bad("a child is not on a lower level than its parent");
+            if (parent[ch] != -1) return bad("a node has two parents");
+            parent[ch] = p;
         }
+    for (int p = 0; p < nn; ++p)
+        if (parent[p] == -1 && h->node_b[p] != 0) return bad("a node without parent has boundary rows");
+    // ---- bands of tree heights that one launch handles (default: one height each) --------------------
+    std::vector<int> cuts;
+    if (h->band_ptr) {
+        if (h->n_bands < 1 || h->n_bands > h->n_levels) return bad("n_bands");
+        for (int k = 0; k <= h->n_bands; ++k) cuts.push_back(h->band_ptr[k]);
+        if (cuts.front() != 0 || cuts.back() != h->n_levels) return bad("band_ptr must run from 0 to n_levels");
+        for (int k = 0; k < h->n_bands; ++k)
+            if (cuts[k + 1] <= cuts[k] || cuts[k + 1] - cuts[k] > 4) return bad("a band holds 1 to 4 tree heights");
+    } else {
+        for (int l = 0; l <= h->n_levels; ++l) cuts.push_back(l);
+    }
 
     DOTS_HIP(hipStreamSynchronize(c->stream));
     front_release(c);
-    // ---- node records, elimination order, update planes ------------------------------------------------
+    // ---- the original tree: node records of the factorisation, elimination order --------------------
     std::vector<FrontNode> nodes((size_t)nn);
-    std::vector<int> vmap((size_t)d.V), bd_vertex((size_t)std::max<int64_t>(h->update_rows, 1)), cmap((size_t)std::max<int64_t>(h->update_rows, 1), 0);
-    std::vector<char> seen((size_t)d.V, 0);
-    // W starts with a pad of zeros as long as the two planes of the largest front: nodes without children read their
-    // (absent) children's updates there, so the sweeps need no branch on "has children"
-    int max_front = 1;
-    for (int p = 0; p < nn; ++p) max_front = std::max(max_front, h->node_n[p] + h->node_b[p]);
-    int64_t wrows = 2 * (int64_t)max_front;
+    std::vector<int> vmap0((size_t)d.V), bd_vertex((size_t)std::max<int64_t>(h->update_rows, 1));
     {
+        std::vector<char> seen((size_t)d.V, 0);
         int k0 = 0;
         int64_t soff = 0;
-        bool identity = true;
         for (int p = 0; p < nn; ++p) {
             FrontNode &nd = nodes[(size_t)p];
             nd.n = h->node_n[p];
@@ -325,178 +537,520 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             nd.k0 = k0;
             nd.foff = h->node_foff[p];
             nd.bdoff = h->node_uoff[p];
-            nd.parent_w = -1;
+            nd.parent_w = parent[p];        // the factorisation only asks "< 0: root"
             nd.c0 = h->node_child[2 * p];
             nd.c1 = h->node_child[2 * p + 1];
             nd.ioff = h->node_ioff[p];
             nd.soff = soff;
             soff += (int64_t)nd.b * nd.b;
-            nd.has_children = (h->node_child[2 * p] >= 0 || h->node_child[2 * p + 1] >= 0) ? 1 : 0;
-            nd.woff = nd.has_children ? wrows : 0;
-            if (nd.has_children) wrows += 2 * (int64_t)(nd.n + nd.b);
-            const int64_t io = h->node_ioff[p];
+            nd.has_children = (nd.c0 >= 0 || nd.c1 >= 0) ? 1 : 0;
+            nd.woff = 0;
+            const int64_t io2 = h->node_ioff[p];
             for (int i = 0; i < nd.n; ++i) {
-                const int v = h->front_idx[io + i];
+                const int v = h->front_idx[io2 + i];
                 if (seen[(size_t)v]) return bad("a vertex is eliminated twice");
                 seen[(size_t)v] = 1;
-                vmap[(size_t)(k0 + i)] = v;
-                identity = identity && v == k0 + i;
+                vmap0[(size_t)(k0 + i)] = v;
             }
-            for (int i = 0; i < nd.b; ++i) bd_vertex[(size_t)(nd.bdoff + i)] = h->front_idx[io + nd.n + i];
+            for (int i = 0; i < nd.b; ++i) bd_vertex[(size_t)(nd.bdoff + i)] = h->front_idx[io2 + nd.n + i];
             k0 += nd.n;
         }
-        // the plane a child writes and where its boundary rows sit in the parent's front (from the pull maps)
-        for (int p = 0; p < nn; ++p) {
-            const FrontNode &nd = nodes[(size_t)p];
-            const int64_t io = h->node_ioff[p];
-            const int m = nd.n + nd.b;
+        for (int p = 0; p < nn; ++p)       // every boundary row of a child must be pulled exactly once by its parent
             for (int k = 0; k < 2; ++k) {
                 const int ch = h->node_child[2 * p + k];
                 if (ch < 0) continue;
-                FrontNode &cn = nodes[(size_t)ch];
-                if (cn.parent_w != -1) return bad("a node has two parents");
-                cn.parent_w = nd.woff + (int64_t)k * m;
                 const int32_t *pull = k == 0 ? h->pull0 : h->pull1;
-                std::vector<char> got((size_t)cn.b, 0);
-                for (int fpos = 0; fpos < m; ++fpos) {
-                    const int r = pull[io + fpos];
+                std::vector<char> got((size_t)h->node_b[ch], 0);
+                for (int fpos = 0; fpos < h->node_n[p] + h->node_b[p]; ++fpos) {
+                    const int r = pull[h->node_ioff[p] + fpos];
                     if (r < 0) continue;
                     if (got[(size_t)r]) return bad("a child boundary row is pulled twice");
                     got[(size_t)r] = 1;
-                    cmap[(size_t)(cn.bdoff + r)] = fpos;
                 }
-                for (int r = 0; r < cn.b; ++r)
+                for (int r = 0; r < h->node_b[ch]; ++r)
                     if (!got[(size_t)r]) return bad("a child boundary row is not pulled by its parent");
             }
-        }
-        for (int p = 0; p < nn; ++p)
-            if (nodes[(size_t)p].parent_w == -1 && nodes[(size_t)p].b != 0) return bad("a node without parent has boundary rows");
-        if (identity) vmap.clear();
     }
 
-    // ---- workgroup lists: (node, first row) per level for the forward sweep, (node, first column) backward.
-    // Levels with many rows: 256-thread workgroups of up to 4 rows; the few large nodes near the root: one row
-    // per 1024-thread workgroup, so that the long dot products are split 4x finer.
-    std::vector<FrontWork> fwd, bwd;
-    auto work = [&](int p, int first) {
-        FrontWork w{};
-        w.nd = nodes[(size_t)p];
-        w.first = first;
-        return w;
-    };
-    for (int l = 0; l < h->n_levels; ++l) {
-        int64_t rows = 0, cols = 0;
-        for (int k = h->level_ptr[l]; k < h->level_ptr[l + 1]; ++k) {
-            const int p = h->level_nodes[k];
-            rows += h->node_n[p] + h->node_b[p];
-            cols += h->node_n[p];
+    // ---- the nodes of the sweeps: the members of a band that hang together ----------------------------
+    std::vector<Group> groups;
+    std::vector<int> band_of_level, root_of((size_t)nn), gidx((size_t)nn, -1), off_in((size_t)nn, 0), c0_in((size_t)nn, 0);
+    std::vector<int> vmap, cmap, band_planes;
+    std::vector<MergeMember> members;
+    std::vector<int> member_of((size_t)nn, -1);
+    int64_t merged_entries = 0, scratch_entries = 0;
+    double entries_read = 0.0;
+    for (int attempt = 0;; ++attempt) {
+        const int nb = (int)cuts.size() - 1;
+        band_of_level.assign((size_t)h->n_levels, 0);
+        for (int k = 0; k < nb; ++k)
+            for (int l = cuts[k]; l < cuts[k + 1]; ++l) band_of_level[(size_t)l] = k;
+        auto band = [&](int p) { return band_of_level[(size_t)level_of[p]]; };
+        for (int p = nn - 1; p >= 0; --p) root_of[(size_t)p] = (parent[p] >= 0 && band(parent[p]) == band(p)) ? root_of[(size_t)parent[p]] : p;
+        groups.clear();
+        std::fill(gidx.begin(), gidx.end(), -1);
+        for (int p = 0; p < nn; ++p)
+            if (root_of[(size_t)p] == p) {
+                gidx[(size_t)p] = (int)groups.size();
+                Group G;
+                G.root = p;
+                G.band = band(p);
+                G.b = h->node_b[p];
+                groups.push_back(G);
+            }
+        for (int p = 0; p < nn; ++p) groups[(size_t)gidx[(size_t)root_of[(size_t)p]]].members.push_back(p);
+        merged_entries = scratch_entries = 0;
+        entries_read = 0.0;
+        int k0 = 0;
+        members.clear();
+        std::fill(member_of.begin(), member_of.end(), -1);
+        for (Group &G : groups) {
+            for (int s : G.members) {
+                off_in[(size_t)s] = G.n;
+                int c0 = G.n;
+                for (int k = 0; k < 2; ++k) {
+                    const int ch = h->node_child[2 * s + k];
+                    if (ch >= 0 && root_of[(size_t)ch] == G.root) c0 = std::min(c0, c0_in[(size_t)ch]);
+                }
+                c0_in[(size_t)s] = c0;
+                const double ns = h->node_n[s];
+                entries_read += 0.5 * ns * (ns + 1) + ns * (double)(G.n - c0);
+                G.n += h->node_n[s];
+            }
+            entries_read += (double)G.b * G.n;
+            G.k0 = k0;
+            k0 += G.n;
+            if (G.members.size() == 1) {
+                G.foff = h->node_foff[G.root];
+            } else {
+                G.foff = h->n_entries + merged_entries;
+                merged_entries += (int64_t)(G.n + G.b) * G.n;
+                for (int s : G.members) {          // member records of the merge kernel
+                    MergeMember mm{};
+                    mm.n = h->node_n[s];
+                    mm.b = h->node_b[s];
+                    mm.o = off_in[(size_t)s];
+                    mm.c0 = c0_in[(size_t)s];
+                    mm.foff = h->node_foff[s];
+                    mm.ioff = h->node_ioff[s];
+                    mm.dst = G.foff;
+                    mm.ns = G.n;
+                    mm.ch[0] = mm.ch[1] = -1;
+                    bool inner = false;
+                    for (int k = 0; k < 2; ++k) {
+                        const int ch = h->node_child[2 * s + k];
+                        if (ch >= 0 && root_of[(size_t)ch] == G.root) { mm.ch[k] = member_of[(size_t)ch]; inner = true; }
+                    }
+                    if (s == G.root) {
+                        mm.uin = 2;
+                        mm.uoff = G.foff + (int64_t)G.n * G.n;
+                        mm.ustride = G.n;
+                    } else if (!inner) {
+                        mm.uin = 0;
+                        mm.uoff = mm.foff + (int64_t)mm.n * mm.n;
+                        mm.ustride = mm.n;
+                    } else {
+                        mm.uin = 1;
+                        mm.uoff = scratch_entries;
+                        mm.ustride = mm.o + mm.n - mm.c0;
+                        scratch_entries += (int64_t)mm.b * mm.ustride;
+                    }
+                    member_of[(size_t)s] = (int)members.size();
+                    members.push_back(mm);
+                }
+            }
         }
-        // keep >= ~1000 workgroups where the level allows; at the bottom of the tree (tens of thousands of rows in
-        // small nodes) up to 16 rows per workgroup: the fixed latency chain of a workgroup (descriptor, node
-        // record, loads, fold, store) then covers 4x more bytes
+        // sweep order, positions of the update rows in the parents' fronts, planes
+        vmap.assign((size_t)d.V, 0);
+        cmap.assign((size_t)std::max<int64_t>(h->update_rows, 1), 0);
+        std::vector<int> rowpos((size_t)d.V, -1);
+        band_planes.assign((size_t)nb, 0);
+        int over = -1;
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            Group &G = groups[gi];
+            for (int s : G.members)
+                for (int i = 0; i < h->node_n[s]; ++i) {
+                    const int v = h->front_idx[h->node_ioff[s] + i];
+                    vmap[(size_t)(G.k0 + off_in[(size_t)s] + i)] = v;
+                    rowpos[(size_t)v] = off_in[(size_t)s] + i;
+                }
+            const int64_t iop = h->node_ioff[G.root] + h->node_n[G.root];
+            for (int i = 0; i < G.b; ++i) rowpos[(size_t)h->front_idx[iop + i]] = G.n + i;
+            // nodes below the band that hang from this one: where their update rows land, and a plane for each such
+            // that no two writers of a plane share a row -- the fewest planes (the forward kernel reads every plane of
+            // every column): exact colouring of the conflict graph (at most 16 nodes)
+            std::vector<int> ext;                          // the children's group indices
+            for (int s : G.members)
+                for (int k = 0; k < 2; ++k) {
+                    const int ch = h->node_child[2 * s + k];
+                    if (ch < 0 || root_of[(size_t)ch] == G.root) continue;
+                    const int32_t *pull = k == 0 ? h->pull0 : h->pull1;
+                    const int64_t ios = h->node_ioff[s], uoc = h->node_uoff[ch];
+                    for (int fpos = 0; fpos < h->node_n[s] + h->node_b[s]; ++fpos) {
+                        const int r = pull[ios + fpos];
+                        if (r >= 0) cmap[(size_t)(uoc + r)] = rowpos[(size_t)h->front_idx[ios + fpos]];
+                    }
+                    groups[(size_t)gidx[(size_t)ch]].parent = (int)gi;
+                    ext.push_back(gidx[(size_t)ch]);
+                }
+            const int ne = (int)ext.size();
+            std::vector<uint32_t> clash((size_t)ne, 0);    // bit j: child i and child j write a common row
+            {
+                std::vector<uint32_t> who((size_t)(G.n + G.b), 0);
+                for (int i = 0; i < ne && i < 32; ++i) {
+                    const int ch = groups[(size_t)ext[(size_t)i]].root;
+                    for (int r = 0; r < h->node_b[ch]; ++r) who[(size_t)cmap[(size_t)(h->node_uoff[ch] + r)]] |= 1u << i;
+                }
+                for (uint32_t m2 : who)
+                    for (int i = 0; i < ne && i < 32; ++i)
+                        if (m2 >> i & 1u) clash[(size_t)i] |= m2 & ~(1u << i);
+            }
+            std::vector<int> colour((size_t)ne, -1);
+            int planes = 0;
+            if (ne > 0 && ne <= 20) {
+                std::vector<int> order((size_t)ne);
+                for (int i = 0; i < ne; ++i) order[(size_t)i] = i;
+                std::sort(order.begin(), order.end(), [&](int x, int y) {
+                    const int dx = __builtin_popcount(clash[(size_t)x]), dy = __builtin_popcount(clash[(size_t)y]);
+                    return dx != dy ? dx > dy : x < y;
+                });
+                for (planes = 1; planes <= ne; ++planes) {
+                    std::fill(colour.begin(), colour.end(), -1);
+                    int64_t budget = 200000;      // backtracking steps; beyond: take the next larger count
+                    std::function<bool(int)> place = [&](int at) -> bool {
+                        if (at == ne) return true;
+                        if (--budget < 0) return false;
+                        const int v = order[(size_t)at];
+                        for (int col = 0; col < planes && col <= at; ++col) {     // col <= at: planes are interchangeable
+                            bool free = true;
+                            for (int j = 0; j < ne && free; ++j)
+                                free = !((clash[(size_t)v] >> j & 1u) && colour[(size_t)j] == col);
+                            if (!free) continue;
+                            colour[(size_t)v] = col;
+                            if (place(at + 1)) return true;
+                            colour[(size_t)v] = -1;
+                        }
+                        return false;
+                    };
+                    if (place(0)) break;
+                }
+            } else {                                       // (not reachable with bands of at most 4 heights) one plane each
+                for (int i = 0; i < ne; ++i) colour[(size_t)i] = i;
+                planes = ne;
+            }
+            for (int i = 0; i < ne; ++i) groups[(size_t)ext[(size_t)i]].colour = colour[(size_t)i];
+            G.planes = planes;
+            band_planes[(size_t)G.band] = std::max(band_planes[(size_t)G.band], G.planes);
+            if (G.planes > 8 && over < 0) over = G.band;
+            for (int s : G.members)
+                for (int i = 0; i < h->node_n[s]; ++i) rowpos[(size_t)h->front_idx[h->node_ioff[s] + i]] = -1;
+            for (int i = 0; i < G.b; ++i) rowpos[(size_t)h->front_idx[iop + i]] = -1;
+        }
+        if (over < 0) break;
+        // more than 8 planes on a merged node (cannot happen with one height per band: two children): split that band
+        if (attempt > 64 || cuts[(size_t)over + 1] - cuts[(size_t)over] < 2) return bad("update planes");
+        std::vector<int> split;
+        for (size_t k = 0; k < cuts.size(); ++k) {
+            split.push_back(cuts[k]);
+            if ((int)k == over)
+                for (int l = cuts[k] + 1; l < cuts[k + 1]; ++l) split.push_back(l);
+        }
+        cuts.swap(split);
+    }
+    const int nb = (int)cuts.size() - 1;
+    bool identity = true;
+    for (int k = 0; k < d.V && identity; ++k) identity = vmap[(size_t)k] == k;
+    bool identity0 = true;
+    for (int k = 0; k < d.V && identity0; ++k) identity0 = vmap0[(size_t)k] == k;
+    // planes: the band's bucket (0, 2, 4, 8) of m rows each per node; W starts with a few zero rows (woff = 0 is never read)
+    int64_t wrows = 8;
+    for (int k = 0; k < nb; ++k) {
+        int &bp = band_planes[(size_t)k];
+        bp = bp == 0 ? 0 : (bp <= 2 ? 2 : (bp <= 4 ? 4 : 8));
+        c->front_planes[k] = bp;
+    }
+    for (Group &G : groups) {
+        G.woff = wrows;
+        wrows += (int64_t)band_planes[(size_t)G.band] * (G.n + G.b);
+    }
+
+    // ---- workgroup lists per band: (node, first row) for the forward sweep, (node, first column, row ranges)
+    // backward
+    std::vector<std::vector<int>> by_band((size_t)nb);
+    for (size_t gi = 0; gi < groups.size(); ++gi) by_band[(size_t)groups[gi].band].push_back((int)gi);
+    auto sweep_node = [&](const Group &G) {
+        SweepNode sn{};
+        sn.n = G.n;
+        sn.b = G.b;
+        sn.k0 = G.k0;
+        sn.planes = G.planes;
+        sn.foff = G.foff;
+        sn.woff = G.woff;
+        sn.parent_w = G.parent < 0 ? -1 : groups[(size_t)G.parent].woff + (int64_t)G.colour * (groups[(size_t)G.parent].n + groups[(size_t)G.parent].b);
+        sn.bdoff = h->node_uoff[G.root];
+        return sn;
+    };
+    auto make_fwd = [&](int k, int rb, std::vector<FrontWork> &out) {
+        for (int gi : by_band[(size_t)k]) {
+            const Group &G = groups[(size_t)gi];
+            const SweepNode sn = sweep_node(G);
+            std::vector<int> first_col((size_t)G.n, 0);     // first column of its member's subtree, per separator row
+            for (int s : G.members)
+                for (int i = 0; i < h->node_n[s]; ++i) first_col[(size_t)(off_in[(size_t)s] + i)] = c0_in[(size_t)s];
+            for (int r = 0; r < G.n + G.b; r += rb) {
+                FrontWork w{};
+                w.nd = sn;
+                w.first = r;
+                int lo = r < G.n ? first_col[(size_t)r] : 0;
+                for (int i = r; i < std::min(r + rb, G.n + G.b); ++i) lo = std::min(lo, i < G.n ? first_col[(size_t)i] : 0);
+                w.lo = lo;
+                out.push_back(w);
+            }
+        }
+    };
+    auto make_bwd = [&](int k, int cb, std::vector<FrontWork> &out) {
+        for (int gi : by_band[(size_t)k]) {
+            const Group &G = groups[(size_t)gi];
+            const SweepNode sn = sweep_node(G);
+            for (int s : G.members) {
+                const int o = off_in[(size_t)s], e = o + h->node_n[s];
+                for (int col = o; col < e; col += cb) {
+                    FrontWork w{};
+                    w.nd = sn;
+                    w.first = col;
+                    w.end = e;
+                    int nr = 0;
+                    w.rs[nr] = col;
+                    w.re[nr] = e;
+                    ++nr;
+                    for (int a2 = parent[s]; a2 >= 0 && root_of[(size_t)a2] == G.root; a2 = parent[a2]) {
+                        const int ao = off_in[(size_t)a2], ae = ao + h->node_n[a2];
+                        if (ae == ao) continue;
+                        if (w.re[nr - 1] == ao) w.re[nr - 1] = ae;          // adjacent: one range
+                        else if (nr < 4) {
+                            w.rs[nr] = ao;
+                            w.re[nr] = ae;
+                            ++nr;
+                        }
+                    }
+                    w.lo = nr;
+                    out.push_back(w);
+                }
+            }
+        }
+    };
+    // Threads and rows (columns) per workgroup of each band.  Many rows: 256-thread workgroups of up to 4 rows; few
+    // rows (the large nodes near the root): one row per 1024-thread workgroup, so that the long dot products are split
+    // 4x finer -- as long as those workgroups fit the chip at once (2 per CU); beyond that, more rows per workgroup.
+    std::vector<int64_t> band_rows((size_t)nb, 0), band_cols((size_t)nb, 0);
+    for (int k = 0; k < nb; ++k) {
+        for (int gi : by_band[(size_t)k]) {
+            band_rows[(size_t)k] += groups[(size_t)gi].n + groups[(size_t)gi].b;
+            band_cols[(size_t)k] += groups[(size_t)gi].n;
+        }
         const int rbmax = c->front_rb_max;
         auto block = [rbmax](int64_t total) {
             int b = total >= 4096 ? 4 : (total >= 2048 ? 2 : 1);
             return std::min(b, rbmax);
         };
-        const int rb = block(rows), cb = block(cols);
-        c->front_fwd_rb[l] = rb;
-        c->front_bwd_cb[l] = cb;
-        c->front_fwd_nb[l] = (rows < 1024 && d.TP <= 256) ? 1024 : 256;
-        c->front_bwd_nb[l] = (cols < 1024 && d.TP <= 256) ? 1024 : 256;
-        c->front_fwd_ptr[l] = (int)fwd.size();
-        c->front_bwd_ptr[l] = (int)bwd.size();
-        for (int k = h->level_ptr[l]; k < h->level_ptr[l + 1]; ++k) {
-            const int p = h->level_nodes[k];
-            for (int r = 0; r < h->node_n[p] + h->node_b[p]; r += rb) fwd.push_back(work(p, r));
-            for (int r = 0; r < h->node_n[p]; r += cb) bwd.push_back(work(p, r));
-        }
+        c->front_fwd_rb[k] = block(band_rows[(size_t)k]);
+        c->front_bwd_cb[k] = block(band_cols[(size_t)k]);
+        c->front_fwd_nb[k] = (band_rows[(size_t)k] < 1024 && d.TP <= 256) ? 1024 : 256;
+        c->front_bwd_nb[k] = (band_cols[(size_t)k] < 1024 && d.TP <= 256) ? 1024 : 256;
     }
-    c->front_fwd_ptr[h->n_levels] = (int)fwd.size();
-    c->front_bwd_ptr[h->n_levels] = (int)bwd.size();
+
+    // ---- device: the original tree, the factor, the merged blocks ----------------------------------------
+    FrontDev f0{};      // the original tree as the factorisation sees it
+    f0.n_nodes = nn;
+    f0.n_levels = h->n_levels;
+    int rc;
+#define FUP(dev, field, src, n) if ((rc = front_upload(c, &dev.field, src, (int64_t)(n)))) { front_release(c); return rc; }
+    FUP(f0, nodes, nodes.data(), nn);
+    if (!identity0) FUP(f0, vmap, vmap0.data(), d.V);
+    FUP(f0, bd_vertex, bd_vertex.data(), bd_vertex.size());
+    const int64_t all_entries = h->n_entries + merged_entries;
+    const double *Fall = nullptr;
+    if ((rc = front_upload<double>(c, &Fall, nullptr, all_entries << d.tp_shift))) { front_release(c); return rc; }
+    if (h->values) {
+        hipError_t e = hipMemcpyAsync(const_cast<double *>(Fall), h->values, sizeof(double) * ((size_t)h->n_entries << d.tp_shift), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { front_release(c); return hip_fail(e, "factor upload", __FILE__, __LINE__); }
+    } else {   // numeric factorisation on the device (kernels_factor.hip)
+        std::vector<int> grounded((size_t)d.TP, 0);
+        for (int a = 0; a < h->n_modes; ++a) grounded[(size_t)a] = h->grounded[a] ? 1 : 0;
+        if ((rc = front_factorize(c, h, f0, nodes, const_cast<double *>(Fall), grounded.data()))) { front_release(c); return rc; }
+    }
+    if (!members.empty()) {      // merged bands: one launch per tree height inside a band, children first
+        std::vector<void *> tmp;
+        auto release_tmp = [&]() { for (void *p : tmp) (void)hipFree(p); };
+        auto dalloc = [&](void **out, size_t bytes, const void *host) -> hipError_t {
+            void *p = nullptr;
+            hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 8));
+            if (e != hipSuccess) return e;
+            tmp.push_back(p);
+            *out = p;
+            return host ? hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+        };
+        std::vector<int> order;                      // member records sorted by (band, tree height)
+        std::vector<int> launch_ptr{0};
+        std::vector<int64_t> launch_items;
+        std::vector<int> node_of_member(members.size());
+        for (int p = 0; p < nn; ++p)
+            if (member_of[(size_t)p] >= 0) node_of_member[(size_t)member_of[(size_t)p]] = p;
+        for (int l = 0; l < h->n_levels; ++l) {
+            int64_t items = 0;
+            for (size_t mi = 0; mi < members.size(); ++mi)
+                if (level_of[node_of_member[mi]] == l) {
+                    order.push_back((int)mi);
+                    const MergeMember &mm = members[mi];
+                    items = std::max(items, (int64_t)(mm.n + mm.b) * (mm.o + mm.n - mm.c0));
+                }
+            if ((int)order.size() > launch_ptr.back()) {
+                launch_ptr.push_back((int)order.size());
+                launch_items.push_back(items);
+            }
+        }
+        void *dm = nullptr, *dl = nullptr, *p0 = nullptr, *p1 = nullptr, *sc = nullptr;
+        hipError_t e = dalloc(&dm, sizeof(MergeMember) * members.size(), members.data());
+        if (e == hipSuccess) e = dalloc(&dl, sizeof(int) * order.size(), order.data());
+        if (e == hipSuccess) e = dalloc(&p0, sizeof(int) * (size_t)h->n_front_rows, h->pull0);
+        if (e == hipSuccess) e = dalloc(&p1, sizeof(int) * (size_t)h->n_front_rows, h->pull1);
+        if (e == hipSuccess) e = dalloc(&sc, sizeof(double) * ((size_t)std::max<int64_t>(scratch_entries, 1) << d.tp_shift), nullptr);
+        if (e == hipSuccess) {
+            MergeArgs g{};
+            g.sh = d.tp_shift; g.TP = d.TP; g.ncol = d.cg_ncol;
+            g.F = const_cast<double *>(Fall);
+            g.scratch = (double *)sc;
+            g.pull0 = (const int *)p0; g.pull1 = (const int *)p1;
+            g.mem = (const MergeMember *)dm;
+            const int Q = 256 >> d.tp_shift;
+            for (size_t k = 0; k + 1 < launch_ptr.size(); ++k) {
+                g.list = (const int *)dl + launch_ptr[k];
+                const unsigned bx = (unsigned)std::min<int64_t>(std::max<int64_t>((launch_items[k] + Q - 1) / Q, 1), 2048);
+                hipLaunchKernelGGL(k_merge_member, dim3(bx, (unsigned)(launch_ptr[k + 1] - launch_ptr[k])), dim3(256), 0, c->stream, g);
+            }
+            e = hipGetLastError();
+        }
+        hipError_t e2 = hipStreamSynchronize(c->stream);
+        release_tmp();
+        if (e != hipSuccess || e2 != hipSuccess) { front_release(c); return hip_fail(e != hipSuccess ? e : e2, "merged bands", __FILE__, __LINE__); }
+    }
 
     FrontDev f{};
     f.n_nodes = nn;
-    f.n_levels = h->n_levels;
-    int rc;
-#define FUP(field, src, n) if ((rc = front_upload(c, &f.field, src, (int64_t)(n)))) { front_release(c); return rc; }
-    FUP(nodes, nodes.data(), nn);
-    if (!vmap.empty()) FUP(vmap, vmap.data(), d.V);
-    FUP(bd_vertex, bd_vertex.data(), bd_vertex.size()); FUP(cmap, cmap.data(), cmap.size());
-    if (h->values) {
-        FUP(F, h->values, h->n_entries << d.tp_shift);
-    } else {   // numeric factorisation on the device (kernels_factor.hip)
-        const double *t = nullptr;
-        if ((rc = front_upload<double>(c, &t, nullptr, h->n_entries << d.tp_shift))) { front_release(c); return rc; }
-        std::vector<int> grounded((size_t)d.TP, 0);
-        for (int a = 0; a < h->n_modes; ++a) grounded[(size_t)a] = h->grounded[a] ? 1 : 0;
-        if ((rc = front_factorize(c, h, f, nodes, const_cast<double *>(t), grounded.data()))) { front_release(c); return rc; }
-        f.F = t;
-    }
-    FUP(fwd_desc, fwd.data(), std::max<size_t>(fwd.size(), 1)); FUP(bwd_desc, bwd.data(), std::max<size_t>(bwd.size(), 1));
+    f.n_levels = nb;
+    f.nodes = f0.nodes;
+    f.bd_vertex = f0.bd_vertex;
+    f.F = Fall;
+    if (!identity) FUP(f, vmap, vmap.data(), d.V);
+    FUP(f, cmap, cmap.data(), cmap.size());
     const double *w = nullptr;
     if ((rc = front_upload<double>(c, &w, nullptr, std::max<int64_t>(wrows, 1) << d.tp_shift))) { front_release(c); return rc; }
     f.W = const_cast<double *>(w);
+    c->front_bytes = 2.0 * entries_read * d.cg_ncol * sizeof(double);
+    c->front_bytes_unmerged = 2.0 * entries_unmerged * d.cg_ncol * sizeof(double);
+    if (const char *e = getenv("DOTS_FRONT_CFG")) {      // "fwd:1024x2,256x4,...;bwd:..." one entry per band (A/B measurements)
+        const std::string spec(e);
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            size_t pos = spec.find(sweep == 0 ? "fwd:" : "bwd:");
+            if (pos == std::string::npos) continue;
+            pos += 4;
+            for (int k = 0; k < nb && pos < spec.size() && spec[pos] != ';'; ++k) {
+                int tnb = 0, trb = 0;
+                if (sscanf(spec.c_str() + pos, "%dx%d", &tnb, &trb) == 2 && (tnb == 256 || tnb == 1024) && (trb == 1 || trb == 2 || trb == 4)) {
+                    (sweep == 0 ? c->front_fwd_nb : c->front_bwd_nb)[k] = tnb;
+                    (sweep == 0 ? c->front_fwd_rb : c->front_bwd_cb)[k] = trb;
+                }
+                pos = spec.find_first_of(",;", pos);
+                if (pos == std::string::npos || spec[pos] == ';') break;
+                ++pos;
+            }
+        }
+    }
+    if (getenv("DOTS_FRONT_TUNE")) {     // time every (threads, rows) choice per band and sweep on this device; prints the table
+        std::vector<void *> tmp;
+        double *vec[3] = {nullptr, nullptr, nullptr};
+        bool ok = true;
+        for (int i = 0; i < 3 && ok; ++i) {
+            void *p2 = nullptr;
+            ok = hipMalloc(&p2, sizeof(double) * ((size_t)d.V << d.tp_shift)) == hipSuccess;
+            if (ok) { tmp.push_back(p2); vec[i] = (double *)p2; ok = hipMemsetAsync(p2, 0, sizeof(double) * ((size_t)d.V << d.tp_shift), c->stream) == hipSuccess; }
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ok = ok && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+        const int apply = atoi(getenv("DOTS_FRONT_TUNE"));
+        for (int k = 0; k < nb && ok; ++k)
+            for (int sweep = 0; sweep < 2 && ok; ++sweep) {
+                double best = 1e30;
+                int bnb = 0, brb = 0;
+                fprintf(stderr, "[front tune] band %d (heights %d-%d, %s, %lld %s, planes %d):", k, cuts[(size_t)k], cuts[(size_t)k + 1] - 1, sweep == 0 ? "fwd" : "bwd",
+                        (long long)(sweep == 0 ? band_rows[(size_t)k] : band_cols[(size_t)k]), sweep == 0 ? "rows" : "cols", c->front_planes[k]);
+                for (int tnb : {256, 1024})
+                    for (int trb : {1, 2, 4}) {
+                        if (tnb == 1024 && d.TP > 256) continue;
+                        std::vector<FrontWork> list;
+                        if (sweep == 0) make_fwd(k, trb, list); else make_bwd(k, trb, list);
+                        if (list.empty()) continue;
+                        void *dl = nullptr;
+                        if (hipMalloc(&dl, sizeof(FrontWork) * list.size()) != hipSuccess) { ok = false; break; }
+                        (void)hipMemcpyAsync(dl, list.data(), sizeof(FrontWork) * list.size(), hipMemcpyHostToDevice, c->stream);
+                        const int reps = 20;
+                        for (int rep = -3; rep < reps; ++rep) {
+                            if (rep == 0) (void)hipEventRecord(e0, c->stream);
+                            if (sweep == 0) front_launch_fwd(c, f, (const FrontWork *)dl, (int)list.size(), tnb, trb, c->front_planes[k], vec[0], vec[1]);
+                            else front_launch_bwd(c, f, (const FrontWork *)dl, (int)list.size(), tnb, trb, vec[1], vec[2]);
+                        }
+                        (void)hipEventRecord(e1, c->stream);
+                        (void)hipEventSynchronize(e1);
+                        float ms = 0.f;
+                        (void)hipEventElapsedTime(&ms, e0, e1);
+                        (void)hipFree(dl);
+                        const double us = 1e3 * ms / reps;
+                        const bool cur = tnb == (sweep == 0 ? c->front_fwd_nb : c->front_bwd_nb)[k] && trb == (sweep == 0 ? c->front_fwd_rb : c->front_bwd_cb)[k];
+                        fprintf(stderr, " %dx%d %.2f%s", tnb, trb, us, cur ? "*" : "");
+                        if (us < best) { best = us; bnb = tnb; brb = trb; }
+                    }
+                fprintf(stderr, "  -> %dx%d\n", bnb, brb);
+                if (apply > 1 && bnb) {
+                    (sweep == 0 ? c->front_fwd_nb : c->front_bwd_nb)[k] = bnb;
+                    (sweep == 0 ? c->front_fwd_rb : c->front_bwd_cb)[k] = brb;
+                }
+            }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemsetAsync(f.W, 0, sizeof(double) * ((size_t)std::max<int64_t>(wrows, 1) << d.tp_shift), c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        for (void *p2 : tmp) (void)hipFree(p2);
+    }
+    std::vector<FrontWork> fwd, bwd;
+    for (int k = 0; k < nb; ++k) {
+        c->front_fwd_ptr[k] = (int)fwd.size();
+        c->front_bwd_ptr[k] = (int)bwd.size();
+        make_fwd(k, c->front_fwd_rb[k], fwd);
+        make_bwd(k, c->front_bwd_cb[k], bwd);
+    }
+    c->front_fwd_ptr[nb] = (int)fwd.size();
+    c->front_bwd_ptr[nb] = (int)bwd.size();
+    FUP(f, fwd_desc, fwd.data(), std::max<size_t>(fwd.size(), 1)); FUP(f, bwd_desc, bwd.data(), std::max<size_t>(bwd.size(), 1));
 #undef FUP
     c->front = f;
     c->use_front = 1;
-    c->front_bytes = 2.0 * entries_read * d.cg_ncol * sizeof(double);
+    c->front_heights = h->n_levels;
     return 0;
 }
 
 int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
-    const Dev &d = c->dcg;
     const FrontDev &f = c->front;
     if (f.n_nodes == 0) { set_error("front_solve: no factor installed"); return DOTS_ERR_STATE; }
-    const FrontArgs g{d.tp_shift, d.TP, d.cg_ncol};
-    const bool vm = f.vmap != nullptr;
-    // two modes per lane (16-byte loads): pays where the sweeps are bandwidth-bound (measured: +6 % at torus100k, +13 % at
-    // T = 127; -2 % on the latency-bound sphere10k, where it is left off)
-    const bool v2 = c->front_vec2 && d.TP >= 4 && d.TP <= 128 && (c->front_vec2 > 1 || d.TP >= 64 || c->front_bytes > 1.0e9);
-#define FRONT_FWD(NBV, RBV, LEAFV)                                                                                                 \
-    do {                                                                                                                           \
-        if (v2) {                                                                                                                  \
-            if (vm) hipLaunchKernelGGL((k_front_fwd<NBV, RBV, true, LEAFV, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);  \
-            else hipLaunchKernelGGL((k_front_fwd<NBV, RBV, false, LEAFV, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);    \
-        } else {                                                                                                                   \
-            if (vm) hipLaunchKernelGGL((k_front_fwd<NBV, RBV, true, LEAFV, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);  \
-            else hipLaunchKernelGGL((k_front_fwd<NBV, RBV, false, LEAFV, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, bhat, y);    \
-        }                                                                                                                          \
-    } while (0)
-#define FRONT_BWD(NBV, RBV)                                                                                                        \
-    do {                                                                                                                           \
-        if (v2) {                                                                                                                  \
-            if (vm) hipLaunchKernelGGL((k_front_bwd<NBV, RBV, true, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);  \
-            else hipLaunchKernelGGL((k_front_bwd<NBV, RBV, false, 2>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);    \
-        } else {                                                                                                                   \
-            if (vm) hipLaunchKernelGGL((k_front_bwd<NBV, RBV, true, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);  \
-            else hipLaunchKernelGGL((k_front_bwd<NBV, RBV, false, 1>), dim3(n), dim3(NBV), 0, c->stream, g, f, ptr, blk, y, x);    \
-        }                                                                                                                          \
-    } while (0)
     for (int l = 0; l < f.n_levels; ++l) {
         const int n = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
-        if (n <= 0) continue;
-        const FrontWork *ptr = f.fwd_desc + c->front_fwd_ptr[l];
-        const int blk = c->front_fwd_rb[l];
-        const bool big = c->front_fwd_nb[l] == 1024;
-        if (l == 0) {            // height 0: leaves only
-            if (big) { if (blk == 1) FRONT_FWD(1024, 1, true); else if (blk == 2) FRONT_FWD(1024, 2, true); else FRONT_FWD(1024, 4, true); }
-            else { if (blk == 1) FRONT_FWD(256, 1, true); else if (blk == 2) FRONT_FWD(256, 2, true); else FRONT_FWD(256, 4, true); }
-        } else {
-            if (big) { if (blk == 1) FRONT_FWD(1024, 1, false); else if (blk == 2) FRONT_FWD(1024, 2, false); else FRONT_FWD(1024, 4, false); }
-            else { if (blk == 1) FRONT_FWD(256, 1, false); else if (blk == 2) FRONT_FWD(256, 2, false); else FRONT_FWD(256, 4, false); }
-        }
+        if (n > 0) front_launch_fwd(c, f, f.fwd_desc + c->front_fwd_ptr[l], n, c->front_fwd_nb[l], c->front_fwd_rb[l], c->front_planes[l], bhat, y);
     }
     for (int l = f.n_levels - 1; l >= 0; --l) {
         const int n = c->front_bwd_ptr[l + 1] - c->front_bwd_ptr[l];
-        if (n <= 0) continue;
-        const FrontWork *ptr = f.bwd_desc + c->front_bwd_ptr[l];
-        const int blk = c->front_bwd_cb[l];
-        if (c->front_bwd_nb[l] == 1024) { if (blk == 1) FRONT_BWD(1024, 1); else if (blk == 2) FRONT_BWD(1024, 2); else FRONT_BWD(1024, 4); }
-        else { if (blk == 1) FRONT_BWD(256, 1); else if (blk == 2) FRONT_BWD(256, 2); else FRONT_BWD(256, 4); }
+        if (n > 0) front_launch_bwd(c, f, f.bwd_desc + c->front_bwd_ptr[l], n, c->front_bwd_nb[l], c->front_bwd_cb[l], y, x);
     }
-#undef FRONT_FWD
-#undef FRONT_BWD
     DOTS_HIP(hipGetLastError());
     return 0;
 }

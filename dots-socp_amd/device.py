@@ -346,10 +346,11 @@ class DeviceProblem:
         return self.mg_summary
 
     # ---- direct (multifrontal) solve of the modal problems
-    def setup_frontal(self, eps=0.0, leaf=None, mode_slice=None, numeric="device"):
+    def setup_frontal(self, eps=0.0, leaf=None, mode_slice=None, numeric="device", bands=None):
         """Factorise K + (sigma_a + eps) M for this context's modes on one nested-dissection tree
         (frontal.py) and install the factor: step 1 then runs two triangular sweeps instead of the PCG.
-        ``numeric``: "device" (HIP kernels, the default) or "host" (numpy reference, small meshes only)."""
+        ``numeric``: "device" (HIP kernels, the default) or "host" (numpy reference, small meshes only).
+        ``bands``: tree heights one launch of a sweep handles (frontal.plan_bands; default: the plan's own cuts)."""
         import scipy.sparse as sp
 
         from . import frontal
@@ -367,11 +368,16 @@ class DeviceProblem:
         if sigma.size == 0:
             return None
         pitch = int(self.lib.dots_front_pitch(self._h))
+        p_pitch = max(8, 1 << int(np.ceil(np.log2(p.n_time + 1))))     # the whole problem's pitch (a time slab's own one is smaller)
         if numeric not in ("device", "host"):
             raise ValueError("numeric must be 'device' or 'host'")
         self.set_params(eps=float(eps))      # the device factorisation reads eps from the context
         ff = frontal.factorize(K, p.mass_vert, sigma + float(eps), diss, pitch=pitch, numeric=numeric == "host")
+        if bands is None:
+            bands = diss.bands if diss.bands is not None else frontal.plan_bands(diss, ff.node_n, ff.node_b, p_pitch)
+        bands = np.ascontiguousarray(bands, dtype=np.int32)
         d = _lib.FrontDesc()
+        d.band_ptr, d.n_bands = _ptr(bands, C.c_int32), bands.size - 1
         d.n_nodes, d.n_levels, d.n_modes, d.pitch = ff.node_n.size, ff.level_ptr.size - 1, ff.n_modes, ff.pitch
         d.n_front_rows, d.n_entries, d.update_rows = ff.front_idx.size, ff.stats["factor_entries_per_mode"], ff.update_rows
         flags = np.zeros(ff.n_modes, dtype=np.int32)
@@ -388,6 +394,10 @@ class DeviceProblem:
         _lib.check(self.lib.dots_front_setup(self._h, C.byref(d)), "dots_front_setup")
         self.front_summary = dict(ff.stats)
         self.front_summary["launches_per_solve"] = self.front_launches()
+        info = (C.c_double * 4)()
+        _lib.check(self.lib.dots_front_info(self._h, info), "dots_front_info")
+        self.front_summary.update(bands=[int(x) for x in bands], bytes_per_solve_one_block_per_node=float(info[0]),
+                                  bytes_per_solve_as_installed=float(info[1]))
         return self.front_summary
 
     def front_launches(self):

@@ -41,6 +41,7 @@ class Dissection:
     child: np.ndarray          # (n_nodes, 2) children ids or -1
     parent: np.ndarray         # (n_nodes,)
     height: np.ndarray         # (n_nodes,) 0 for leaves
+    bands: np.ndarray | None = None    # (n_bands+1,) tree heights one launch of a sweep handles (plan_bands); None: one each
 
     @property
     def n_nodes(self):
@@ -189,6 +190,89 @@ def symbolic_native(diss: Dissection, indptr, indices):
     finally:
         lib.dots_symbolic_free(h)
     return node_b, front_idx, pull0, pull1
+
+
+# ------------------------------------------------------------------------------------------------
+# bands of tree heights that one launch of a sweep handles (csrc/kernels_front.hip, "merged heights")
+# ------------------------------------------------------------------------------------------------
+def band_entries(diss: Dissection, node_n, node_b, lo, hi):
+    """(factor entries one sweep reads, front rows, vector entries the forward workgroups read) when the heights
+    [lo, hi) are merged: a member's rows hold its own triangle plus the columns of its descendants inside the band, the
+    top member's boundary rows all columns; every row block of a merged node reads the right-hand side and the update
+    planes of its columns (2, 4 or 8 planes for bands of 1, 2 or more heights above the leaves)."""
+    h, child, parent = diss.height, diss.child, diss.parent
+    n = np.asarray(node_n, dtype=np.int64)
+    b = np.asarray(node_b, dtype=np.int64)
+    inb = (h >= lo) & (h < hi)
+    desc = np.zeros(n.size, dtype=np.int64)
+    entries = rows = 0
+    tops = []
+    for p in np.flatnonzero(inb):          # ascending = children first
+        for c in child[p]:
+            if c >= 0 and inb[c]:
+                desc[p] += desc[c] + n[c]
+        entries += n[p] * (n[p] + 1) // 2 + n[p] * desc[p]
+        if parent[p] < 0 or not inb[parent[p]]:
+            entries += b[p] * (desc[p] + n[p])
+            rows += desc[p] + n[p] + b[p]
+            tops.append((int(desc[p] + n[p]), int(b[p])))
+    planes = 0 if lo == 0 else (2 if hi - lo == 1 else (4 if hi - lo == 2 else 8))
+    rb = 4 if rows >= 4096 else (2 if rows >= 2048 else 1)
+    vec = sum((0.5 * nm * nm + nm * bm) / rb * (1 + planes) for nm, bm in tops)
+    return int(entries), int(rows), float(vec)
+
+
+# cost model of one launch of a sweep, fitted to the solve times of ~2 000 band cuts measured on MI355X (meshes of 2.5 k to
+# 41 k vertices, T = 31 and 63; profiles/studies/band_cuts.txt): microseconds = launch + factor MB / 5.3 TB/s + vector MB / 67 TB/s
+BAND_LAUNCH_US = (4.5, 8.0)     # small factors (cache resident) ... factors of 1 GB and more
+BAND_FACTOR_TBS = 5.3
+BAND_VECTOR_TBS = 67.0
+
+
+def plan_bands(diss: Dissection, node_n, node_b, pitch, max_heights=4, spec=None):
+    """Cut the tree heights into bands, each handled by ONE launch per sweep: the cuts that minimise the modelled solve
+    time (see BAND_* above).  On small meshes a launch per height costs more than the bytes it streams, so two to four
+    heights are merged per band; on large ones (bandwidth-bound) almost nothing is.  ``spec`` (or the environment
+    variable DOTS_FRONT_BANDS): "auto", "off", or explicit cuts "0,2,5,8,10".  Depends on the tree and the pitch of the
+    whole problem only, so that every rank of a sharded run cuts alike."""
+    import os
+
+    H = int(diss.height.max()) + 1
+    spec = os.environ.get("DOTS_FRONT_BANDS", "auto") if spec is None else spec
+    if spec == "off":
+        return np.arange(H + 1, dtype=np.int32)
+    if spec != "auto":
+        cuts = np.asarray([int(x) for x in str(spec).split(",")], dtype=np.int32)
+        if cuts[0] != 0 or cuts[-1] != H or np.any(np.diff(cuts) < 1) or np.any(np.diff(cuts) > max_heights):
+            raise ValueError(f"bad band cuts {spec!r} for a tree of {H} heights")
+        return cuts
+    unit = float(pitch) * 8.0
+    n = np.asarray(node_n, dtype=np.int64)
+    b = np.asarray(node_b, dtype=np.int64)
+    total = float((n * (n + 1) // 2 + b * n).sum()) * unit * 2.0
+    launch_us = BAND_LAUNCH_US[0] + (BAND_LAUNCH_US[1] - BAND_LAUNCH_US[0]) * min(1.0, total / 1.0e9)
+    cost = {}
+    for hi in range(1, H + 1):
+        for lo in range(max(0, hi - max_heights), hi):
+            e, rows, vec = band_entries(diss, n, b, lo, hi)
+            cost[(lo, hi)] = launch_us + (e + 3.0 * rows) * unit / (BAND_FACTOR_TBS * 1e6) + vec * unit / (BAND_VECTOR_TBS * 1e6)
+    best = {0: (0.0, [0])}
+    for hi in range(1, H + 1):
+        best[hi] = min((best[lo][0] + cost[(lo, hi)], best[lo][1] + [hi]) for lo in range(max(0, hi - max_heights), hi))
+    return np.asarray(best[H][1], dtype=np.int32)
+
+
+def sweep_order(diss: Dissection, bands):
+    """Vertex sequence of the sweeps: the separators of the nodes of a band that hang together are consecutive
+    (sorted by the band's top node, then by node).  With bands of one height this is the elimination order."""
+    h, parent = diss.height, diss.parent
+    band_of = np.searchsorted(np.asarray(bands), h, side="right") - 1
+    root = np.arange(diss.n_nodes)
+    for p in range(diss.n_nodes - 1, -1, -1):
+        if parent[p] >= 0 and band_of[parent[p]] == band_of[p]:
+            root[p] = root[parent[p]]
+    seq = np.lexsort((np.arange(diss.n_nodes), root))
+    return np.concatenate([diss.order[diss.sep_ptr[p]:diss.sep_ptr[p + 1]] for p in seq])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -124,18 +124,21 @@ def locality_order(K, triangles):
     return perm_v, perm_f
 
 
-def dissection_order(K, vertices, triangles, leaf=16):
-    """Nested-dissection numbering (the elimination order of the direct solver, frontal.py): leaves are
-    compact patches of the surface, so it is also a locality-preserving numbering for the gathers."""
+def dissection_order(K, vertices, triangles, leaf=16, pitch=32):
+    """Nested-dissection numbering (the order in which the sweeps of the direct solver walk the vertices, frontal.py:
+    the elimination order, with the separators of merged tree heights pulled together): leaves are compact patches of
+    the surface, so it is also a locality-preserving numbering for the gathers."""
     from . import frontal
 
     diss = frontal.nested_dissection(K.indptr, K.indices, vertices, leaf=leaf)
-    perm_v = diss.order.astype(np.int64)
+    node_b = frontal.symbolic_native(diss, K.indptr, K.indices)[0]
+    diss.bands = frontal.plan_bands(diss, np.diff(diss.sep_ptr), node_b, pitch)
+    perm_v = frontal.sweep_order(diss, diss.bands).astype(np.int64)
     inv = np.empty_like(perm_v)
     inv[perm_v] = np.arange(perm_v.size)
     t_new = inv[np.asarray(triangles)]
     perm_f = np.argsort(t_new.min(axis=1), kind="stable")
-    diss.order = np.arange(perm_v.size, dtype=np.int64)      # in the new numbering the order is the identity
+    diss.order = inv[diss.order]      # elimination order in the new numbering (the identity when no heights are merged)
     return perm_v, perm_f, diss
 
 
@@ -155,7 +158,8 @@ def build_plan(n_time, geometry, reorder=True, nd_leaf=16) -> DevicePlan:
     if reorder:
         K0 = mesh_adjacency(V, triangles)
         if reorder == "nd":
-            perm_v, perm_f, diss = dissection_order(K0, vertices, triangles, leaf=nd_leaf)
+            pitch = max(8, 1 << int(np.ceil(np.log2(n_time + 1))))
+            perm_v, perm_f, diss = dissection_order(K0, vertices, triangles, leaf=nd_leaf, pitch=pitch)
         else:
             perm_v, perm_f = locality_order(K0, triangles)
         inv = np.empty_like(perm_v)

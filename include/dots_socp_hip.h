@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DOTS_ABI_VERSION 2
+#define DOTS_ABI_VERSION 3
 
 typedef struct dots_ctx dots_ctx;
 
@@ -346,6 +346,11 @@ typedef struct dots_front_desc {
     const double *values;        /* the factor, or NULL: factorise K + (sigma_a + eps) M on the device (eps from dots_params) */
     const int32_t *grounded;     /* [n_modes] 1: the mode's operator is singular (its last root pivot is grounded);
                                     read when values == NULL */
+    const int32_t *band_ptr;     /* [n_bands+1] or NULL: tree heights [band_ptr[k], band_ptr[k+1]) are handled by ONE launch
+                                    per sweep (0 = band_ptr[0] < ... < band_ptr[n_bands] = n_levels, at most 4 heights per
+                                    band): the nodes of a band that hang together are merged into one block, computed on
+                                    the device from the factor (csrc/kernels_front.hip).  NULL: one launch per height */
+    int32_t n_bands;
 } dots_front_desc;
 
 int dots_front_setup(dots_ctx *ctx, const dots_front_desc *desc);
@@ -371,8 +376,12 @@ int64_t dots_symbolic_front_rows(const dots_symbolic *sym);
 int dots_symbolic_copy(const dots_symbolic *sym, int32_t *node_b, int32_t *front_idx, int32_t *pull0, int32_t *pull1);
 void dots_symbolic_free(dots_symbolic *sym);
 int dots_front_enable(dots_ctx *ctx, int on);
-/* launches one direct solve takes: 2 x tree height (one per height and sweep) */
+/* launches one direct solve takes: 2 x bands of tree heights (one per band and sweep; a band is one height unless
+ * dots_front_desc.band_ptr merges heights) */
 int dots_front_launches(dots_ctx *ctx);
+/* out[4]: factor bytes one solve reads with one block per tree node (both sweeps: the algorithmic bytes of the solve),
+ * the bytes it reads as installed (merged bands store more), tree heights, bands */
+int dots_front_info(dots_ctx *ctx, double *out);
 /* the mode pitch `values` must be laid out with (power of two >= the context's mode count, >= 8) */
 int dots_front_pitch(dots_ctx *ctx);
 

@@ -32,8 +32,8 @@ def test_tree_and_structure(name, kw, reorder):
     V = plan.n_vertices
     diss = plan.dissection if reorder == "nd" else frontal.nested_dissection(K.indptr, K.indices, plan.vertices, leaf=8,
                                                                              native=reorder != "python")
-    if reorder == "nd":
-        assert np.array_equal(diss.order, np.arange(V))      # the device numbering IS the elimination order
+    if reorder == "nd":      # the device numbering IS the order in which the sweeps walk the vertices
+        assert np.array_equal(frontal.sweep_order(diss, diss.bands), np.arange(V))
     assert np.array_equal(np.sort(diss.order), np.arange(V))
     assert diss.parent[-1] == -1 and np.all(diss.parent[:-1] > np.arange(diss.n_nodes - 1))
     # separator property: no edge joins the two subtrees of a node
@@ -100,3 +100,30 @@ def test_native_dissection_is_at_least_as_good_as_the_reference_one():
         d = frontal.nested_dissection(K.indptr, K.indices, plan.vertices, leaf=16, native=native)
         size[native] = frontal.factorize(K, plan.mass_vert, plan.time_eigs[:1] + 1.0, d, numeric=False).stats["factor_entries_per_mode"]
     assert size[True] <= 1.05 * size[False]
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+@pytest.mark.parametrize("cuts", ["pairs", "triples", "all", [0, 2, 3]])
+def test_merged_heights_solve_the_same_systems(name, kw, cuts):
+    """The merged form of the sweeps (dots_front_desc.band_ptr, csrc/kernels_merge.hip) restated in numpy: the blocks of a
+    band of tree heights are combined algebraically, the solution is the unmerged one to rounding."""
+    plan, K = problem(name, "nd", **kw)
+    shifts = plan.time_eigs[:3] + 0.0
+    ff = frontal.factorize(K, plan.mass_vert, shifts, plan.dissection, workers=1)
+    H = ff.level_ptr.size - 1
+    if cuts == "pairs":
+        cuts = [0] + list(range(1, H, 2)) + [H]
+    elif cuts == "triples":
+        cuts = sorted(set([0, 1] + list(range(H, 1, -3))))
+    elif cuts == "all":
+        cuts = [0, H]
+    else:
+        cuts = sorted(set(cuts + [H]))
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal((plan.n_vertices, shifts.size))
+    b[:, 0] -= b[:, 0].mean()
+    x0 = frontal_cpu.solve(ff, b)
+    bands = frontal_cpu.merge(ff, cuts)
+    assert sum(g["sep"].size for band in bands for g in band) == plan.n_vertices
+    x1 = frontal_cpu.solve_merged(ff, bands, b)
+    assert np.max(np.abs(x1 - x0)) < 1e-10 * np.max(np.abs(x0))

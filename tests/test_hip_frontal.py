@@ -136,3 +136,48 @@ def test_pcg_alternatives_at_large_time_pitch(T, prec):
         out[tag] = dev.download("phi")
         dev.close()
     assert rel(out["pcg"], out["direct"]) < 1e-8
+
+
+@pytest.mark.parametrize("mesh,kw,T,eps", [("sphere", dict(level=4), 15, 0.0), ("torus", dict(nu=72, nv=40), 31, 1e-3), ("knot", dict(nu=240, nv=10), 63, 0.0)])
+def test_merged_tree_heights_give_the_same_solution(mesh, kw, T, eps):
+    """Bands of tree heights handled by one launch per sweep (dots_front_desc.band_ptr, csrc/kernels_front.hip: the blocks of
+    a band are merged on the device from the factor): every cut -- pairs, triples, four heights, ragged ones, on the
+    plan's numbering and on a foreign one (index map in the sweeps) -- solves the systems like one launch per height, and
+    a solve takes 2 x bands launches.  A band of five heights is refused."""
+    from dots_socp_amd import _lib
+
+    geom, _ = meshes.example(mesh, **kw)
+    out, launches = {}, {}
+    H = None
+    for tag, reorder, cuts in (("off", "nd", "unit"), ("auto", "nd", None), ("pairs", "nd", 2), ("triples", "nd", 3), ("fours", "nd", 4),
+                               ("ragged", "nd", "ragged"), ("rcm_triples", True, 3), ("host_pairs", "nd", 2)):
+        dev = make(geom, T, eps, reorder)
+        if H is None:
+            H = int(dev.plan.dissection.height.max()) + 1
+        if cuts == "unit":
+            bands = np.arange(H + 1)
+        elif cuts == "ragged":
+            bands = np.asarray(sorted(set(x for x in (0, 1, 4, 5, H - 1, H) if 0 <= x <= H)))
+            if np.any(np.diff(bands) > 4):
+                bands = np.asarray(sorted(set(range(0, H, 3)) | {H}))
+        elif cuts is None:
+            bands = None
+        else:      # from the top: `cuts` heights per band, the leaves' band takes the rest
+            bands = np.asarray(sorted(set(range(H, 0, -cuts)) | {0}))
+        s = dev.setup_frontal(eps=eps, bands=bands, numeric="host" if tag.startswith("host") else "device")
+        assert s["launches_per_solve"] == 2 * (len(s["bands"]) - 1)
+        assert s["bytes_per_solve_as_installed"] >= s["bytes_per_solve_one_block_per_node"] * (1.0 - 1e-12)
+        launches[tag] = s["launches_per_solve"]
+        st = dev.run_phase("laplacian")
+        assert st.cg_not_converged == 0
+        phi = dev.download("phi")
+        assert np.all(np.isfinite(phi)), tag
+        mass = dev.plan.mass_vert[np.argsort(dev.plan.perm_vert)]
+        out[tag] = gauge(phi, mass) if eps == 0.0 else phi
+        if tag == "fours":
+            with pytest.raises(_lib.HipLibraryError, match="band"):
+                dev.setup_frontal(eps=eps, bands=np.asarray([0, 5, H]) if H > 5 else np.asarray([0, H + 1]))
+        dev.close()
+    assert launches["off"] == 2 * H and launches["pairs"] < launches["off"] and launches["fours"] <= launches["triples"] <= launches["pairs"]
+    for tag in out:
+        assert rel(out[tag], out["off"]) < 1e-10, tag
