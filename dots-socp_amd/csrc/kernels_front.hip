@@ -165,8 +165,9 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
     const int last = row0 + nr - 1;
     const int jmax = last < n ? last + 1 : n;
     // U steps of the dot product are loaded before the first is used (merged nodes have long rows: a step per
-    // memory round trip would leave the workgroup waiting on latency)
-    constexpr int U = !DOTS_FRONT_UNROLL ? 1 : ((1 + KP + RB) * VEC <= 6) ? 4 : (((1 + KP + RB) * VEC <= 12) ? 2 : 1);
+    // memory round trip would leave the workgroup waiting on latency).  One-mode lanes only: measured +1...7 % on the
+    // merged small meshes, -2 % on the bandwidth-bound two-mode sweeps of torus100k (profiles/studies/band_cuts.txt)
+    constexpr int U = (!DOTS_FRONT_UNROLL || VEC > 1) ? 1 : ((1 + KP + RB) <= 6) ? 4 : (((1 + KP + RB) <= 12) ? 2 : 1);
     if (live) {
         for (int j0 = wk.lo + q; j0 < jmax; j0 += U * Q) {
             Vd<VEC> wb[U], wp[U][KP > 0 ? KP : 1], fv[U][RB];
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const
         for (int c = 0; c < VEC; ++c) acc[r].v[c] = 0.0;
         co[r] = (int64_t)(r < nc ? col0 + r : col0) << sh;
     }
-    constexpr int U = !DOTS_FRONT_UNROLL ? 1 : ((1 + RB) * VEC <= 4) ? 4 : (((1 + RB) * VEC <= 10) ? 2 : 1);      // as in the forward sweep
+    constexpr int U = (!DOTS_FRONT_UNROLL || VEC > 1) ? 1 : ((1 + RB) <= 4) ? 4 : 2;      // as in the forward sweep
     if (live) {
         // rows of the separators: y.  Column i of L^-1 is zero above the diagonal: start at the block's first column
 #pragma unroll
@@ -839,24 +840,32 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             }
         }
     };
-    // Threads and rows (columns) per workgroup of each band.  Many rows: 256-thread workgroups of up to 4 rows; few
-    // rows (the large nodes near the root): one row per 1024-thread workgroup, so that the long dot products are split
-    // 4x finer -- as long as those workgroups fit the chip at once (2 per CU); beyond that, more rows per workgroup.
+    // Threads and rows (columns) per workgroup of each band (measured per band with DOTS_FRONT_TUNE, profiles/studies/
+    // band_cuts.txt).  Many rows: 256-thread workgroups of up to 4 rows; few rows (the large nodes near the root): 1024-thread
+    // workgroups, so that the long dot products are split 4x finer.  Forward bands whose nodes read 4 or 8 update planes take
+    // 4 rows per workgroup earlier (the planes are read once per workgroup, not per row).
     std::vector<int64_t> band_rows((size_t)nb, 0), band_cols((size_t)nb, 0);
     for (int k = 0; k < nb; ++k) {
         for (int gi : by_band[(size_t)k]) {
             band_rows[(size_t)k] += groups[(size_t)gi].n + groups[(size_t)gi].b;
             band_cols[(size_t)k] += groups[(size_t)gi].n;
         }
-        const int rbmax = c->front_rb_max;
-        auto block = [rbmax](int64_t total) {
-            int b = total >= 4096 ? 4 : (total >= 2048 ? 2 : 1);
-            return std::min(b, rbmax);
-        };
-        c->front_fwd_rb[k] = block(band_rows[(size_t)k]);
-        c->front_bwd_cb[k] = block(band_cols[(size_t)k]);
-        c->front_fwd_nb[k] = (band_rows[(size_t)k] < 1024 && d.TP <= 256) ? 1024 : 256;
-        c->front_bwd_nb[k] = (band_cols[(size_t)k] < 1024 && d.TP <= 256) ? 1024 : 256;
+        const int64_t rows = band_rows[(size_t)k], cols = band_cols[(size_t)k];
+        const bool big_ok = d.TP <= 256;      // 1024-thread workgroups need a row of modes to fit
+        int fnb, frb, bnb, bcb;
+        if (band_planes[(size_t)k] >= 4) {
+            if (rows >= 600 || !big_ok) { fnb = 256; frb = 4; }
+            else { fnb = 1024; frb = rows >= 300 ? 2 : 1; }
+        } else {
+            frb = rows >= 4096 ? 4 : (rows >= 2048 ? 2 : 1);
+            fnb = (rows < 1024 && big_ok) ? 1024 : 256;
+        }
+        if (cols >= 1536 || !big_ok) { bnb = 256; bcb = cols >= 4096 ? 4 : (cols >= 2048 ? 2 : 1); }
+        else { bnb = 1024; bcb = cols >= 400 ? 2 : 1; }
+        c->front_fwd_rb[k] = std::min(frb, c->front_rb_max);
+        c->front_bwd_cb[k] = std::min(bcb, c->front_rb_max);
+        c->front_fwd_nb[k] = fnb;
+        c->front_bwd_nb[k] = bnb;
     }
 
     // ---- device: the original tree, the factor, the merged blocks ----------------------------------------

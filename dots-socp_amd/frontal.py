@@ -223,9 +223,11 @@ def band_entries(diss: Dissection, node_n, node_b, lo, hi):
 
 
 # cost model of one launch of a sweep, fitted to the solve times of ~2 000 band cuts measured on MI355X (meshes of 2.5 k to
-# 41 k vertices, T = 31 and 63; profiles/studies/band_cuts.txt): microseconds = launch + factor MB / 5.3 TB/s + vector MB / 67 TB/s
+# 41 k vertices, T = 31 and 63; profiles/studies/band_cuts.txt): microseconds = launch + factor MB / (5.3 TB/s) + vector MB / (67 TB/s)
+# (on factors far beyond the 256 MB Infinity Cache the sweeps stream at 3.7-4.4 TB/s and a merge that adds bytes loses:
+# torus65k_T127 with heights 1-2 and 11-12 merged 1.771 ms against 1.690 ms)
 BAND_LAUNCH_US = (4.5, 8.0)     # small factors (cache resident) ... factors of 1 GB and more
-BAND_FACTOR_TBS = 5.3
+BAND_FACTOR_TBS = (5.3, 3.0)
 BAND_VECTOR_TBS = 67.0
 
 
@@ -250,12 +252,14 @@ def plan_bands(diss: Dissection, node_n, node_b, pitch, max_heights=4, spec=None
     n = np.asarray(node_n, dtype=np.int64)
     b = np.asarray(node_b, dtype=np.int64)
     total = float((n * (n + 1) // 2 + b * n).sum()) * unit * 2.0
-    launch_us = BAND_LAUNCH_US[0] + (BAND_LAUNCH_US[1] - BAND_LAUNCH_US[0]) * min(1.0, total / 1.0e9)
+    big = min(1.0, total / 1.0e9)
+    launch_us = BAND_LAUNCH_US[0] + (BAND_LAUNCH_US[1] - BAND_LAUNCH_US[0]) * big
+    factor_tbs = BAND_FACTOR_TBS[0] + (BAND_FACTOR_TBS[1] - BAND_FACTOR_TBS[0]) * min(1.0, max(0.0, total - 1.0e9) / 2.0e9)
     cost = {}
     for hi in range(1, H + 1):
         for lo in range(max(0, hi - max_heights), hi):
             e, rows, vec = band_entries(diss, n, b, lo, hi)
-            cost[(lo, hi)] = launch_us + (e + 3.0 * rows) * unit / (BAND_FACTOR_TBS * 1e6) + vec * unit / (BAND_VECTOR_TBS * 1e6)
+            cost[(lo, hi)] = launch_us + e * unit / (factor_tbs * 1e6) + (vec + 3.0 * rows) * unit / (BAND_VECTOR_TBS * 1e6)
     best = {0: (0.0, [0])}
     for hi in range(1, H + 1):
         best[hi] = min((best[lo][0] + cost[(lo, hi)], best[lo][1] + [hi]) for lo in range(max(0, hi - max_heights), hi))
