@@ -1,4 +1,4 @@
-"""Cost of the sharded iteration (begin / all-gather / end) on ONE GPU: a single rank that owns all modes, and two / four
+"""Cost of the time-slab iteration (dots_slab_stage 0-3 with its three exchanges) on ONE GPU: a single rank that owns all nodes and modes, and two
 ranks as threads sharing the GPU (their kernels serialise, so only the 1-rank line is a timing; the others check that the
 path runs).  usage: python profiles/studies/sharded_overhead.py [workload]"""
 import os

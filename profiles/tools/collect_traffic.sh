@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${w}_$c -o s -- python bench.py --no-cpu-baseline --no-time-to-tol --no-configs --steps 20 --warmup 5 --workload $w > $out/pmc_${w}_$c.json 2> $out/pmc_${w}_$c.log
 done
-levels=$(python -c "import json;print(json.load(open('$out/pmc_${w}_FETCH_SIZE.json'))['roofline']['factor']['levels'])")
+levels=$(python -c "import json;print(json.load(open('$out/pmc_${w}_FETCH_SIZE.json'))['roofline']['launches_per_solve'] // 2)")   # forward launches of one solve = bands of tree heights
 calib=$(python -c "import json;print(json.load(open('$out/pmc_${w}_FETCH_SIZE.json'))['roofline']['pmc_calibration_bytes_each_way'])")
 python profiles/tools/pmc_summary.py $out/pmc_${w}_FETCH_SIZE/s_counter_collection.csv $out/pmc_${w}_WRITE_SIZE/s_counter_collection.csv $out/pmc_${w}_summary.json --calib k_calib_stream $calib $calib --front-levels $levels > $out/pmc_${w}_summary.txt
 python - <<PY
@@ -19,6 +19,8 @@ b = json.load(open("$out/pmc_${w}_FETCH_SIZE.json"))
 json.dump({"bytes_per_solve": s["front_solve"]["bytes_per_solve"], "read_bytes_per_solve": s["front_solve"]["read_bytes_per_solve"],
            "written_bytes_per_solve": s["front_solve"]["written_bytes_per_solve"],
            "algorithmic_bytes_per_solve": b["roofline"]["algorithmic_bytes_per_solve"],
+           "factor_bytes_per_solve_as_installed": b["roofline"]["factor"].get("bytes_per_solve_as_installed"),
+           "bands": b["roofline"]["factor"].get("bands"),
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) of 'bench.py --workload $w --steps 20 --warmup 5 --no-configs', commit $commit, "
                      "calibrated on k_calib_stream of the same run (profiles/tools/collect_traffic.sh)"},
           open("$out/traffic_${w}.json", "w"), indent=1)
