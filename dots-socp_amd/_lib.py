@@ -120,6 +120,24 @@ def library_path() -> str:
     return LIB_PATH
 
 
+def _torch_runtime_first():
+    """PyTorch-ROCm wheels bundle their own HIP runtime.  When both runtimes live in one process (torch.distributed for the
+    exchanges of distributed.py, the tests' device buffers), torch must initialise its runtime BEFORE this library touches the
+    device: the other order leaves torch with "No HIP GPUs are available" (measured on MI355X / ROCm 7.2 with torch 2.10+rocm7.0).
+    If torch is already imported, initialise it here; a process that imports torch only later must call torch.cuda.init() itself
+    before it creates a context."""
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return
+    try:
+        if torch.cuda.is_available() and not torch.cuda.is_initialized():
+            torch.cuda.init()
+    except Exception:  # pragma: no cover - a torch without devices is not this library's business
+        pass
+
+
 def load():
     """Load the shared library (once) and declare the signatures."""
     global _lib
@@ -130,6 +148,7 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m dots_socp_amd.build` (hipcc, gfx950). "
             "dots-socp_amd has no CPU fallback."
         )
+    _torch_runtime_first()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the host

@@ -416,19 +416,28 @@ __device__ __forceinline__ void modes_from_tile_mfma(const Dev &d, const double 
 // Qeff[i][j] = Q[i][j] (FWD: time -> modes) or Q[j][i] (modes -> time), staged through Qs in chunks of IC rows.
 // A thread computes up to four outputs that share their Q column.  All threads of the workgroup must call it.
 // Only the outputs j in [j0, j0 + jn) are stored, at y[(v << out_shift) + (j - j0)]  (defaults: all of them, pitch TP).
+// rows [i0, i0 + ic) of Qeff into Qs.  A caller may stage the first chunk itself BEFORE its own loads of the tile (staged0):
+// the Q loads then overlap them instead of adding a memory round trip behind the first barrier.
+template <bool FWD, int NB = BLOCK>
+__device__ __forceinline__ void stage_q_chunk(const Dev &d, const double *Q, double *Qs, int i0, int ic) {
+    const int n = d.T + 1, TP = d.TP;
+    for (int e = threadIdx.x; e < ic * TP; e += NB) {
+        const int i = i0 + (e >> d.tp_shift), jj = e & (TP - 1);
+        Qs[e] = jj < n ? (FWD ? Q[i * n + jj] : Q[jj * n + i]) : 0.0;
+    }
+}
 template <bool FWD, int NB = BLOCK>
 __device__ __forceinline__ void modes_from_tile(const Dev &d, const double *Q, const double *xs, double *Qs, int IC, int v0, double *__restrict__ y,
-                                                int out_shift = -1, int j0 = 0, int jn = 1 << 30) {
+                                                int out_shift = -1, int j0 = 0, int jn = 1 << 30, bool staged0 = false) {
     if (out_shift < 0) out_shift = d.tp_shift;
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1, tid = threadIdx.x;
     const int j = tid & (TP - 1), g = tid >> d.tp_shift, G = NB >> d.tp_shift;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i0 = 0; i0 < n; i0 += IC) {
         const int ic = min(IC, n - i0);
-        __syncthreads();      // the previous chunk (or the caller's staging of xs) is complete
-        for (int e = tid; e < ic * TP; e += NB) {
-            const int i = i0 + (e >> d.tp_shift), jj = e & (TP - 1);
-            Qs[e] = jj < n ? (FWD ? Q[i * n + jj] : Q[jj * n + i]) : 0.0;
+        if (!(staged0 && i0 == 0)) {
+            __syncthreads();      // the previous chunk (or the caller's staging of xs) is complete
+            stage_q_chunk<FWD, NB>(d, Q, Qs, i0, ic);
         }
         __syncthreads();
         if (j < n && g < d.VT) {

@@ -251,11 +251,12 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double ep
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
     const int v0 = tile * d.VT;
+    stage_q_chunk<true, RHS_NB>(d, d.Q, Qs, 0, min(IC, n));      // in flight while the corner walks run
     for (int e = threadIdx.x; e < TILE_ELEMS; e += RHS_NB) {
         const int vl = e >> d.tp_shift, t = e & (TP - 1);
         xs[vl * TPp + t] = (v0 + vl < d.V && t < n) ? rhs_value(d, v0 + vl, t, r, eps) : 0.0;
     }
-    modes_from_tile<true, RHS_NB>(d, d.Q, xs, Qs, IC, v0, bhat);
+    modes_from_tile<true, RHS_NB>(d, d.Q, xs, Qs, IC, v0, bhat, -1, 0, 1 << 30, true);
 }
 
 // T + 1 >= 64: 32 vertices per workgroup, the transform on the matrix cores.

@@ -428,8 +428,9 @@ __global__ __launch_bounds__(BLOCK) void k_time_modes(Dev d, const double *__res
 // The same transform with the tile of x and Q (in chunks) staged in LDS: every x row and every Q entry is read
 // from memory once per workgroup instead of once per output; a thread computes four outputs that share their Q
 // column.  x rows are padded by one double so that the rows a wavefront broadcasts sit in different banks.
-template <bool FWD>
-__global__ __launch_bounds__(BLOCK) void k_time_modes_tile(Dev d, const double *__restrict__ x, double *__restrict__ y, int IC) {
+// NB = 1024 (one output per thread) where the launch is latency-bound: the inverse transform after the direct solve.
+template <bool FWD, int NB = BLOCK>
+__global__ __launch_bounds__(NB) void k_time_modes_tile(Dev d, const double *__restrict__ x, double *__restrict__ y, int IC) {
     extern __shared__ double tm_lds[];
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
     double *Qs = tm_lds;                 // [IC][TP]
@@ -437,11 +438,12 @@ __global__ __launch_bounds__(BLOCK) void k_time_modes_tile(Dev d, const double *
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
     const int v0 = tile * d.VT;
-    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+    stage_q_chunk<FWD, NB>(d, d.Q, Qs, 0, min(IC, n));      // together with the tile's loads: one round trip, one barrier
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += NB) {
         const int vl = e >> d.tp_shift, t = e & (TP - 1);
         xs[vl * TPp + t] = (v0 + vl < d.V && t < n) ? x[idxV(d, v0 + vl, t)] : 0.0;
     }
-    modes_from_tile<FWD>(d, d.Q, xs, Qs, IC, v0, y);
+    modes_from_tile<FWD, NB>(d, d.Q, xs, Qs, IC, v0, y, -1, 0, 1 << 30, true);
 }
 
 // The transform as a GEMM on the matrix cores (T + 1 >= 64; modes_from_tile_mfma in dots_dev.h): a workgroup
@@ -775,6 +777,8 @@ static int cg_solve_impl(Ctx *c, dots_step_stats *stats, bool defer_inverse) {
         if (time_modes_mfma_ok(d))
             hipLaunchKernelGGL(k_time_modes_mfma, dim3((d.V + TM_ROWS - 1) / TM_ROWS), dim3(BLOCK), sizeof(double) * TM_ROWS * (d.TP + 1), c->stream, d, d.QpadT,
                                d.cg_x, d.phi);
+        else if (time_modes_tile_ok(d) && direct && d.n_vtiles <= 512)      // small meshes, behind the sweeps: latency-bound, one output per thread (knot: 9.5 -> 6 us; no gain at 10^5 vertices)
+            hipLaunchKernelGGL((k_time_modes_tile<false, 1024>), dim3(gt), dim3(1024), time_modes_tile_lds(d), c->stream, d, d.cg_x, d.phi, time_modes_chunk(d));
         else if (time_modes_tile_ok(d))
             hipLaunchKernelGGL((k_time_modes_tile<false>), dim3(gt), dim3(BLOCK), time_modes_tile_lds(d), c->stream, d, d.cg_x, d.phi, time_modes_chunk(d));
         else

@@ -37,6 +37,14 @@ def has_gpu():
         return False
 
 
+# The GPU tests that stage exchange buffers in torch tensors need torch's (bundled) HIP runtime initialised before the
+# product library touches the device (dots-socp_amd/_lib.py: _torch_runtime_first): do it once, whatever file runs first.
+if has_gpu():
+    import torch
+
+    torch.cuda.init()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     return load_oracle()
