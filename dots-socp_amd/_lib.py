@@ -10,7 +10,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libdotsocp_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ARRAY_IDS = {
     "phi": 0, "A": 1, "B": 2, "lambda_c": 3, "z_fst": 4, "z_mid": 5, "z_end": 6,
@@ -87,7 +87,7 @@ class FrontDesc(C.Structure):
         ("node_n", _i32p), ("node_b", _i32p), ("node_foff", C.POINTER(C.c_int64)), ("node_ioff", C.POINTER(C.c_int64)),
         ("node_uoff", C.POINTER(C.c_int64)), ("node_child", _i32p), ("front_idx", _i32p), ("pull0", _i32p), ("pull1", _i32p),
         ("level_ptr", _i32p), ("level_nodes", _i32p), ("values", _f64p), ("grounded", _i32p),
-        ("band_ptr", _i32p), ("n_bands", C.c_int32),
+        ("band_ptr", _i32p), ("n_bands", C.c_int32), ("top_inverse", C.c_int32),
     ]
 
 

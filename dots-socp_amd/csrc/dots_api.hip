@@ -839,7 +839,7 @@ int dots_front_enable(dots_ctx *c, int on) {
 
 int dots_front_launches(dots_ctx *c) {
     if (check(c) || c->front.n_nodes == 0) return -1;
-    return 2 * c->front.n_levels;
+    return 2 * c->front.n_levels - (c->front_top_inverse ? 1 : 0);
 }
 
 int dots_front_info(dots_ctx *c, double *out) {

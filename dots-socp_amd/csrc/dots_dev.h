@@ -146,7 +146,8 @@ struct FrontWork {
     int first;                // first row (forward) / first column (backward) of the block
     int lo;                   // forward: first column that can be nonzero in the block's rows; backward: number of row ranges
     int rs[4], re[4];         // backward: separator-row ranges [rs, re) that can be nonzero in the block's columns (rs[0] = first)
-    int end;                  // backward: one past the last column of the block's member
+    int end;                  // backward: one past the last column of the block's member; forward: > 0 = every row of the block runs over
+                              // the columns [lo, end) (a node that stores an explicit inverse), 0 = up to the diagonal
     int pad;
 };
 // One original node inside a merged band node (k_merge_member builds F' from the members' own blocks)
@@ -275,6 +276,7 @@ struct Ctx {
     double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps, merged blocks as stored)
     double front_bytes_unmerged = 0.0;   // the same for one launch per tree height (no merged bands)
     int front_heights = 0;        // tree heights of the installed factor
+    int front_top_inverse = 0;    // the top band holds explicit inverses: its forward launch writes x, the backward sweep skips it
     void *front_allocs[48]{};
     int n_front_allocs = 0;
     void *mg_allocs[160]{};

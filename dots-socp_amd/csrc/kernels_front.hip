@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
     // rows of L^-1 only need the columns j <= i: the block's last row bounds the loop; wk.lo: the first column of the
     // block's rows that is not in a zero block of the merged node
     const int last = row0 + nr - 1;
-    const int jmax = last < n ? last + 1 : n;
+    const int jmax = wk.end > 0 ? wk.end : (last < n ? last + 1 : n);
     // U steps of the dot product are loaded before the first is used (merged nodes have long rows: a step per
     // memory round trip would leave the workgroup waiting on latency).  One-mode lanes only: measured +1...7 % on the
     // merged small meshes, -2 % on the bandwidth-bound two-mode sweeps of torus100k (profiles/studies/band_cuts.txt)
@@ -380,6 +380,36 @@ __global__ __launch_bounds__(256) void k_merge_member(MergeArgs g) {
     }
 }
 
+// ---- top band as an explicit inverse (dots_front_desc.top_inverse): S^-1 = L'^-T L'^-1 of a node without boundary rows ----
+// grid (blocks of entries, nodes); thread = (mode, entry (i, j)); L = the node's merged block, row stride n
+struct TopInvArgs {
+    int sh, TP, ncol;
+    const double *F;
+    double *out;                // S^-1 of every node of the list, one after the other
+    const int64_t *foff, *ooff; // per node: its block in F, its block in out
+    const int *n;
+};
+__global__ __launch_bounds__(256) void k_top_inverse(TopInvArgs g) {
+    const int nd = blockIdx.y, n = g.n[nd];
+    const int sh = g.sh, tid = threadIdx.x;
+    const int a = tid & (g.TP - 1), q = tid >> sh, Q = 256 >> sh;
+    if (a >= g.ncol) return;
+    const double *__restrict__ L = g.F + (g.foff[nd] << sh) + a;
+    double *__restrict__ S = g.out + (g.ooff[nd] << sh) + a;
+    const int64_t total = (int64_t)n * n;
+    for (int64_t e = (int64_t)blockIdx.x * Q + q; e < total; e += (int64_t)gridDim.x * Q) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        double s0 = 0.0, s1 = 0.0;
+        int k = max(i, j);
+        for (; k + 2 <= n; k += 2) {
+            s0 += L[((int64_t)k * n + i) << sh] * L[((int64_t)k * n + j) << sh];
+            s1 += L[((int64_t)(k + 1) * n + i) << sh] * L[((int64_t)(k + 1) * n + j) << sh];
+        }
+        for (; k < n; ++k) s0 += L[((int64_t)k * n + i) << sh] * L[((int64_t)k * n + j) << sh];
+        S[e << sh] = s0 + s1;
+    }
+}
+
 // two modes per lane (16-byte loads): pays where the sweeps are bandwidth-bound (measured: +6 % at torus100k, +13 % at
 // T = 127; -2 % on the latency-bound sphere10k, where it is left off)
 static bool front_two_modes(const Ctx *c) {
@@ -441,6 +471,7 @@ void front_release(Ctx *c) {
     c->use_front = 0;
     c->front_bytes = c->front_bytes_unmerged = 0.0;
     c->front_heights = 0;
+    c->front_top_inverse = 0;
 }
 
 namespace {
@@ -521,6 +552,8 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     } else {
         for (int l = 0; l <= h->n_levels; ++l) cuts.push_back(l);
     }
+
+    const bool top_inv = h->top_inverse != 0;      // the top band stores explicit inverses (its nodes have no boundary rows)
 
     DOTS_HIP(hipStreamSynchronize(c->stream));
     front_release(c);
@@ -619,6 +652,11 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
                 G.n += h->node_n[s];
             }
             entries_read += (double)G.b * G.n;
+            if (top_inv && G.band == nb - 1) {     // S^-1: n x n entries read ONCE per solve = n * n / 2 per sweep in this count
+                double tri = 0.0;
+                for (int s : G.members) tri += 0.5 * h->node_n[s] * (h->node_n[s] + 1.0) + (double)h->node_n[s] * (off_in[(size_t)s] - c0_in[(size_t)s]);
+                entries_read += 0.5 * (double)G.n * G.n - tri;
+            }
             G.k0 = k0;
             k0 += G.n;
             if (G.members.size() == 1) {
@@ -805,6 +843,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
                 int lo = r < G.n ? first_col[(size_t)r] : 0;
                 for (int i = r; i < std::min(r + rb, G.n + G.b); ++i) lo = std::min(lo, i < G.n ? first_col[(size_t)i] : 0);
                 w.lo = lo;
+                if (top_inv && k == nb - 1) { w.lo = 0; w.end = G.n; }     // full rows of S^-1
                 out.push_back(w);
             }
         }
@@ -853,7 +892,10 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         const int64_t rows = band_rows[(size_t)k], cols = band_cols[(size_t)k];
         const bool big_ok = d.TP <= 256;      // 1024-thread workgroups need a row of modes to fit
         int fnb, frb, bnb, bcb;
-        if (band_planes[(size_t)k] >= 4) {
+        if (top_inv && k == nb - 1 && big_ok) {      // full rows of S^-1: every workgroup reads the whole right-hand side and all planes
+            fnb = 1024;
+            frb = rows >= 480 ? 4 : (rows >= 64 ? 2 : 1);
+        } else if (band_planes[(size_t)k] >= 4) {
             if (rows >= 600 || !big_ok) { fnb = 256; frb = 4; }
             else { fnb = 1024; frb = rows >= 300 ? 2 : 1; }
         } else {
@@ -945,6 +987,48 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         if (e != hipSuccess || e2 != hipSuccess) { front_release(c); return hip_fail(e != hipSuccess ? e : e2, "merged bands", __FILE__, __LINE__); }
     }
 
+    if (top_inv) {      // the top band's blocks L'^-1 (n x n, no boundary rows) become S^-1 = L'^-T L'^-1, in place
+        std::vector<int64_t> foffs, ooffs;
+        std::vector<int> ns;
+        int64_t total = 0, biggest = 0;
+        for (int gi : by_band[(size_t)(nb - 1)]) {
+            const Group &G = groups[(size_t)gi];
+            if (G.b != 0) { front_release(c); return bad("top_inverse: a node of the top band has boundary rows"); }
+            if (G.n == 0) continue;
+            foffs.push_back(G.foff);
+            ooffs.push_back(total);
+            ns.push_back(G.n);
+            total += (int64_t)G.n * G.n;
+            biggest = std::max<int64_t>(biggest, (int64_t)G.n * G.n);
+        }
+        if (!ns.empty()) {
+            void *dS = nullptr, *dfo = nullptr, *doo = nullptr, *dn = nullptr;
+            hipError_t e = hipMalloc(&dS, sizeof(double) * ((size_t)total << d.tp_shift));
+            if (e == hipSuccess) e = hipMalloc(&dfo, sizeof(int64_t) * foffs.size());
+            if (e == hipSuccess) e = hipMalloc(&doo, sizeof(int64_t) * ooffs.size());
+            if (e == hipSuccess) e = hipMalloc(&dn, sizeof(int) * ns.size());
+            if (e == hipSuccess) e = hipMemcpyAsync(dfo, foffs.data(), sizeof(int64_t) * foffs.size(), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(doo, ooffs.data(), sizeof(int64_t) * ooffs.size(), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(dn, ns.data(), sizeof(int) * ns.size(), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) {
+                TopInvArgs g{};
+                g.sh = d.tp_shift; g.TP = d.TP; g.ncol = d.cg_ncol;
+                g.F = Fall; g.out = (double *)dS;
+                g.foff = (const int64_t *)dfo; g.ooff = (const int64_t *)doo; g.n = (const int *)dn;
+                const int Q = 256 >> d.tp_shift;
+                const unsigned bx = (unsigned)std::min<int64_t>(std::max<int64_t>((biggest + Q - 1) / Q, 1), 4096);
+                hipLaunchKernelGGL(k_top_inverse, dim3(bx, (unsigned)ns.size()), dim3(256), 0, c->stream, g);
+                e = hipGetLastError();
+                for (size_t k = 0; k < ns.size() && e == hipSuccess; ++k)
+                    e = hipMemcpyAsync(const_cast<double *>(Fall) + (foffs[k] << d.tp_shift), (const double *)dS + (ooffs[k] << d.tp_shift),
+                                       sizeof(double) * ((size_t)ns[k] * ns[k] << d.tp_shift), hipMemcpyDeviceToDevice, c->stream);
+            }
+            hipError_t e2 = hipStreamSynchronize(c->stream);
+            for (void *p2 : {dS, dfo, doo, dn}) if (p2) (void)hipFree(p2);
+            if (e != hipSuccess || e2 != hipSuccess) { front_release(c); return hip_fail(e != hipSuccess ? e : e2, "top inverse", __FILE__, __LINE__); }
+        }
+    }
+
     FrontDev f{};
     f.n_nodes = nn;
     f.n_levels = nb;
@@ -990,6 +1074,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         const int apply = atoi(getenv("DOTS_FRONT_TUNE"));
         for (int k = 0; k < nb && ok; ++k)
             for (int sweep = 0; sweep < 2 && ok; ++sweep) {
+                if (sweep == 1 && top_inv && k == nb - 1) continue;      // no backward launch there
                 double best = 1e30;
                 int bnb = 0, brb = 0;
                 fprintf(stderr, "[front tune] band %d (heights %d-%d, %s, %lld %s, planes %d):", k, cuts[(size_t)k], cuts[(size_t)k + 1] - 1, sweep == 0 ? "fwd" : "bwd",
@@ -1046,6 +1131,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     c->front = f;
     c->use_front = 1;
     c->front_heights = h->n_levels;
+    c->front_top_inverse = top_inv ? 1 : 0;
     return 0;
 }
 
@@ -1054,9 +1140,11 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
     if (f.n_nodes == 0) { set_error("front_solve: no factor installed"); return DOTS_ERR_STATE; }
     for (int l = 0; l < f.n_levels; ++l) {
         const int n = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
-        if (n > 0) front_launch_fwd(c, f, f.fwd_desc + c->front_fwd_ptr[l], n, c->front_fwd_nb[l], c->front_fwd_rb[l], c->front_planes[l], bhat, y);
+        // (a top band of explicit inverses writes the solution itself)
+        if (n > 0) front_launch_fwd(c, f, f.fwd_desc + c->front_fwd_ptr[l], n, c->front_fwd_nb[l], c->front_fwd_rb[l], c->front_planes[l], bhat,
+                                    (c->front_top_inverse && l == f.n_levels - 1) ? x : y);
     }
-    for (int l = f.n_levels - 1; l >= 0; --l) {
+    for (int l = f.n_levels - 1 - (c->front_top_inverse ? 1 : 0); l >= 0; --l) {
         const int n = c->front_bwd_ptr[l + 1] - c->front_bwd_ptr[l];
         if (n > 0) front_launch_bwd(c, f, f.bwd_desc + c->front_bwd_ptr[l], n, c->front_bwd_nb[l], c->front_bwd_cb[l], y, x);
     }

@@ -346,11 +346,12 @@ class DeviceProblem:
         return self.mg_summary
 
     # ---- direct (multifrontal) solve of the modal problems
-    def setup_frontal(self, eps=0.0, leaf=None, mode_slice=None, numeric="device", bands=None):
+    def setup_frontal(self, eps=0.0, leaf=None, mode_slice=None, numeric="device", bands=None, top_inverse=None):
         """Factorise K + (sigma_a + eps) M for this context's modes on one nested-dissection tree
         (frontal.py) and install the factor: step 1 then runs two triangular sweeps instead of the PCG.
         ``numeric``: "device" (HIP kernels, the default) or "host" (numpy reference, small meshes only).
-        ``bands``: tree heights one launch of a sweep handles (frontal.plan_bands; default: the plan's own cuts)."""
+        ``bands``: tree heights one launch of a sweep handles, ``top_inverse``: the top band as explicit inverses, one launch
+        for both sweeps (frontal.plan_bands; default: the plan's own choice)."""
         import scipy.sparse as sp
 
         from . import frontal
@@ -374,10 +375,15 @@ class DeviceProblem:
         self.set_params(eps=float(eps))      # the device factorisation reads eps from the context
         ff = frontal.factorize(K, p.mass_vert, sigma + float(eps), diss, pitch=pitch, numeric=numeric == "host")
         if bands is None:
-            bands = diss.bands if diss.bands is not None else frontal.plan_bands(diss, ff.node_n, ff.node_b, p_pitch)
+            if diss.bands is not None:
+                bands, auto_top = diss.bands, diss.top_inverse
+            else:
+                bands, auto_top = frontal.plan_bands(diss, ff.node_n, ff.node_b, p_pitch)
+            if top_inverse is None:
+                top_inverse = auto_top
         bands = np.ascontiguousarray(bands, dtype=np.int32)
         d = _lib.FrontDesc()
-        d.band_ptr, d.n_bands = _ptr(bands, C.c_int32), bands.size - 1
+        d.band_ptr, d.n_bands, d.top_inverse = _ptr(bands, C.c_int32), bands.size - 1, 1 if top_inverse else 0
         d.n_nodes, d.n_levels, d.n_modes, d.pitch = ff.node_n.size, ff.level_ptr.size - 1, ff.n_modes, ff.pitch
         d.n_front_rows, d.n_entries, d.update_rows = ff.front_idx.size, ff.stats["factor_entries_per_mode"], ff.update_rows
         flags = np.zeros(ff.n_modes, dtype=np.int32)
@@ -396,7 +402,7 @@ class DeviceProblem:
         self.front_summary["launches_per_solve"] = self.front_launches()
         info = (C.c_double * 4)()
         _lib.check(self.lib.dots_front_info(self._h, info), "dots_front_info")
-        self.front_summary.update(bands=[int(x) for x in bands], bytes_per_solve_one_block_per_node=float(info[0]),
+        self.front_summary.update(bands=[int(x) for x in bands], top_inverse=bool(top_inverse), bytes_per_solve_one_block_per_node=float(info[0]),
                                   bytes_per_solve_as_installed=float(info[1]))
         return self.front_summary
 

@@ -42,6 +42,7 @@ class Dissection:
     parent: np.ndarray         # (n_nodes,)
     height: np.ndarray         # (n_nodes,) 0 for leaves
     bands: np.ndarray | None = None    # (n_bands+1,) tree heights one launch of a sweep handles (plan_bands); None: one each
+    top_inverse: bool = False          # the top band stores explicit inverses: one launch for both sweeps (plan_bands)
 
     @property
     def n_nodes(self):
@@ -222,48 +223,94 @@ def band_entries(diss: Dissection, node_n, node_b, lo, hi):
     return int(entries), int(rows), float(vec)
 
 
-# cost model of one launch of a sweep, fitted to the solve times of ~2 000 band cuts measured on MI355X (meshes of 2.5 k to
-# 41 k vertices, T = 31 and 63; profiles/studies/band_cuts.txt): microseconds = launch + factor MB / (5.3 TB/s) + vector MB / (67 TB/s)
-# (on factors far beyond the 256 MB Infinity Cache the sweeps stream at 3.7-4.4 TB/s and a merge that adds bytes loses:
-# torus65k_T127 with heights 1-2 and 11-12 merged 1.771 ms against 1.690 ms)
-BAND_LAUNCH_US = (4.5, 8.0)     # small factors (cache resident) ... factors of 1 GB and more
-BAND_FACTOR_TBS = (5.3, 3.0)
-BAND_VECTOR_TBS = 67.0
+# Cost model of the sweeps, fitted to the solve times of ~3 000 cuts measured on MI355X (meshes of 2.5 k to 41 k vertices,
+# T = 31 and 63, with and without the explicit top inverse; profiles/studies/band_cuts.txt).  Microseconds per launch:
+#     launch + factor MB / bandwidth + steps * BAND_STEP_US        steps = columns of the longest row / 32
+# The longest row is the serial part of a launch (a row is split over 32 lanes per mode); the bandwidth a factor is
+# streamed at falls with its size (cache-resident ... far beyond the 256 MB Infinity Cache).
+BAND_LAUNCH_US = (3.7, 8.0)     # small factors ... factors of 1 GB and more (more workgroup rounds per launch)
+BAND_FACTOR_TBS = ((1.0e8, 7.3), (3.0e8, 5.3), (1.0e9, 4.5), (3.0e9, 3.0))      # (factor bytes read per solve, TB/s)
+BAND_STEP_US = 0.45
+BAND_VECTOR_TBS = 67.0          # right-hand side and update planes re-read by every row block (L2)
 
 
-def plan_bands(diss: Dissection, node_n, node_b, pitch, max_heights=4, spec=None):
+def _factor_tbs(total):
+    pts = BAND_FACTOR_TBS
+    if total <= pts[0][0]:
+        return pts[0][1]
+    for (x0, y0), (x1, y1) in zip(pts[:-1], pts[1:]):
+        if total <= x1:
+            w = (np.log(total) - np.log(x0)) / (np.log(x1) - np.log(x0))
+            return y0 + w * (y1 - y0)
+    return pts[-1][1]
+
+
+def plan_bands(diss: Dissection, node_n, node_b, pitch, max_heights=4, spec=None, top_spec=None):
     """Cut the tree heights into bands, each handled by ONE launch per sweep: the cuts that minimise the modelled solve
     time (see BAND_* above).  On small meshes a launch per height costs more than the bytes it streams, so two to four
-    heights are merged per band; on large ones (bandwidth-bound) almost nothing is.  ``spec`` (or the environment
-    variable DOTS_FRONT_BANDS): "auto", "off", or explicit cuts "0,2,5,8,10".  Depends on the tree and the pitch of the
-    whole problem only, so that every rank of a sharded run cuts alike."""
+    heights are merged per band; on large ones (bandwidth-bound) almost nothing is.  Returns (cuts, top_inverse):
+    ``top_inverse`` = the top band (its nodes have no boundary rows) stores the explicit inverse S^-1 = L'^-T L'^-1 of its
+    merged block, read ONCE per solve by a single launch instead of L'^-1 twice by two (n^2 entries against ~n^2 / 2 twice:
+    the same bytes, one launch less -- and a larger top band becomes affordable).
+    ``spec`` (or the environment variable DOTS_FRONT_BANDS): "auto", "off", or explicit cuts "0,2,5,8,10"; ``top_spec``
+    (DOTS_FRONT_TOPINV): "auto", "0", "1".  Depends on the tree and the pitch of the whole problem only, so that every rank
+    of a sharded run cuts alike."""
     import os
 
     H = int(diss.height.max()) + 1
     spec = os.environ.get("DOTS_FRONT_BANDS", "auto") if spec is None else spec
+    top_spec = os.environ.get("DOTS_FRONT_TOPINV", "auto") if top_spec is None else str(top_spec)
     if spec == "off":
-        return np.arange(H + 1, dtype=np.int32)
+        return np.arange(H + 1, dtype=np.int32), top_spec == "1"
     if spec != "auto":
         cuts = np.asarray([int(x) for x in str(spec).split(",")], dtype=np.int32)
         if cuts[0] != 0 or cuts[-1] != H or np.any(np.diff(cuts) < 1) or np.any(np.diff(cuts) > max_heights):
             raise ValueError(f"bad band cuts {spec!r} for a tree of {H} heights")
-        return cuts
+        return cuts, top_spec == "1"
     unit = float(pitch) * 8.0
     n = np.asarray(node_n, dtype=np.int64)
     b = np.asarray(node_b, dtype=np.int64)
     total = float((n * (n + 1) // 2 + b * n).sum()) * unit * 2.0
     big = min(1.0, total / 1.0e9)
     launch_us = BAND_LAUNCH_US[0] + (BAND_LAUNCH_US[1] - BAND_LAUNCH_US[0]) * big
-    factor_tbs = BAND_FACTOR_TBS[0] + (BAND_FACTOR_TBS[1] - BAND_FACTOR_TBS[0]) * min(1.0, max(0.0, total - 1.0e9) / 2.0e9)
-    cost = {}
+    factor_tbs = _factor_tbs(total)
+    cost, inv_cost = {}, {}
     for hi in range(1, H + 1):
         for lo in range(max(0, hi - max_heights), hi):
             e, rows, vec = band_entries(diss, n, b, lo, hi)
-            cost[(lo, hi)] = launch_us + e * unit / (factor_tbs * 1e6) + (vec + 3.0 * rows) * unit / (BAND_VECTOR_TBS * 1e6)
-    best = {0: (0.0, [0])}
+            tops = _band_tops(diss, n, lo, hi)
+            steps = max(tops) / 32.0
+            cost[(lo, hi)] = launch_us + e * unit / (factor_tbs * 1e6) + (vec + 3.0 * rows) * unit / (BAND_VECTOR_TBS * 1e6) * big \
+                + 0.75 * steps * BAND_STEP_US
+            if hi == H and top_spec != "0":       # per sweep: half of ONE launch that reads n^2 entries per node, in full rows
+                full = float(sum(t * t for t in tops))
+                inv_cost[lo] = 0.5 * (launch_us + full * unit / (factor_tbs * 1e6) + steps * BAND_STEP_US)
+    best = {0: (0.0, [0], False)}
     for hi in range(1, H + 1):
-        best[hi] = min((best[lo][0] + cost[(lo, hi)], best[lo][1] + [hi]) for lo in range(max(0, hi - max_heights), hi))
-    return np.asarray(best[H][1], dtype=np.int32)
+        cands = []
+        for lo in range(max(0, hi - max_heights), hi):
+            cands.append((best[lo][0] + cost[(lo, hi)], best[lo][1] + [hi], False))
+            if hi == H and lo in inv_cost and top_spec in ("auto", "1"):
+                cands.append((best[lo][0] + inv_cost[lo], best[lo][1] + [hi], True))
+        if hi == H and top_spec == "1":
+            cands = [c for c in cands if c[2]] or cands
+        best[hi] = min(cands, key=lambda c: c[0])
+    return np.asarray(best[H][1], dtype=np.int32), bool(best[H][2])
+
+
+def _band_tops(diss: Dissection, n, lo, hi):
+    """columns of the merged nodes of the band of heights [lo, hi)"""
+    h, child, parent = diss.height, diss.child, diss.parent
+    inb = (h >= lo) & (h < hi)
+    desc = np.zeros(n.size, dtype=np.int64)
+    tops = []
+    for p in np.flatnonzero(inb):
+        for c in child[p]:
+            if c >= 0 and inb[c]:
+                desc[p] += desc[c] + n[c]
+        if parent[p] < 0 or not inb[parent[p]]:
+            tops.append(int(desc[p] + n[p]))
+    return tops
 
 
 def sweep_order(diss: Dissection, bands):

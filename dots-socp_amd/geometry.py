@@ -132,7 +132,7 @@ def dissection_order(K, vertices, triangles, leaf=16, pitch=32):
 
     diss = frontal.nested_dissection(K.indptr, K.indices, vertices, leaf=leaf)
     node_b = frontal.symbolic_native(diss, K.indptr, K.indices)[0]
-    diss.bands = frontal.plan_bands(diss, np.diff(diss.sep_ptr), node_b, pitch)
+    diss.bands, diss.top_inverse = frontal.plan_bands(diss, np.diff(diss.sep_ptr), node_b, pitch)
     perm_v = frontal.sweep_order(diss, diss.bands).astype(np.int64)
     inv = np.empty_like(perm_v)
     inv[perm_v] = np.arange(perm_v.size)

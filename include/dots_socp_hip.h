@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DOTS_ABI_VERSION 3
+#define DOTS_ABI_VERSION 4
 
 typedef struct dots_ctx dots_ctx;
 
@@ -351,6 +351,10 @@ typedef struct dots_front_desc {
                                     band): the nodes of a band that hang together are merged into one block, computed on
                                     the device from the factor (csrc/kernels_front.hip).  NULL: one launch per height */
     int32_t n_bands;
+    int32_t top_inverse;         /* 1: the nodes of the top band (they have no boundary rows) store the explicit inverse
+                                    S^-1 = L'^-T L'^-1 of their merged block: the forward launch of that band writes the
+                                    solution itself and the backward sweep starts one band lower (one launch less per solve;
+                                    pays on small meshes, where the top band is a few hundred rows) */
 } dots_front_desc;
 
 int dots_front_setup(dots_ctx *ctx, const dots_front_desc *desc);
@@ -377,7 +381,7 @@ int dots_symbolic_copy(const dots_symbolic *sym, int32_t *node_b, int32_t *front
 void dots_symbolic_free(dots_symbolic *sym);
 int dots_front_enable(dots_ctx *ctx, int on);
 /* launches one direct solve takes: 2 x bands of tree heights (one per band and sweep; a band is one height unless
- * dots_front_desc.band_ptr merges heights) */
+ * dots_front_desc.band_ptr merges heights), minus one with dots_front_desc.top_inverse */
 int dots_front_launches(dots_ctx *ctx);
 /* out[4]: factor bytes one solve reads with one block per tree node (both sweeps: the algorithmic bytes of the solve),
  * the bytes it reads as installed (merged bands store more), tree heights, bands */

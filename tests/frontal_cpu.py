@@ -131,23 +131,30 @@ def merge(ff, cuts):
     return bands
 
 
-def solve_merged(ff, bands, rhs):
+def solve_merged(ff, bands, rhs, top_inverse=False):
+    """``top_inverse``: the nodes of the top band (no boundary rows) hold S^-1 = L'^-T L'^-1 instead of L'^-1: their forward
+    step already gives x, the backward sweep starts one band lower (dots_front_desc.top_inverse)."""
     A = ff.n_modes
     y = np.zeros((ff.n_vertices, A))
     x = np.zeros((ff.n_vertices, A))
     u = {}
-    for band in bands:
+    for k, band in enumerate(bands):
         for g in band:
             n, b = g["sep"].size, g["bd"].size
             acc = np.zeros((n + b, A))
             for c, rows in g["children"]:
                 acc[rows] += u.pop(c)
+            if top_inverse and k == len(bands) - 1:
+                assert b == 0
+                Sinv = np.einsum("kia,kja->ija", g["F"], g["F"])
+                x[g["sep"]] = np.einsum("ija,ja->ia", Sinv, rhs[g["sep"]] - acc)
+                continue
             out = np.einsum("ija,ja->ia", g["F"], rhs[g["sep"]] - acc[:n])
             y[g["sep"]] = out[:n]
             if b:
                 u[g["node"]] = acc[n:] + out[n:]
     assert not u
-    for band in bands[::-1]:
+    for band in (bands[:-1] if top_inverse else bands)[::-1]:
         for g in band:
             v = np.concatenate([y[g["sep"]], -x[g["bd"]]], axis=0)
             x[g["sep"]] = np.einsum("jia,ja->ia", g["F"], v)

@@ -127,3 +127,5 @@ def test_merged_heights_solve_the_same_systems(name, kw, cuts):
     assert sum(g["sep"].size for band in bands for g in band) == plan.n_vertices
     x1 = frontal_cpu.solve_merged(ff, bands, b)
     assert np.max(np.abs(x1 - x0)) < 1e-10 * np.max(np.abs(x0))
+    x2 = frontal_cpu.solve_merged(ff, bands, b, top_inverse=True)      # the top band as one explicit inverse
+    assert np.max(np.abs(x2 - x0)) < 1e-10 * np.max(np.abs(x0))

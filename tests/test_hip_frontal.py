@@ -143,14 +143,16 @@ def test_merged_tree_heights_give_the_same_solution(mesh, kw, T, eps):
     """Bands of tree heights handled by one launch per sweep (dots_front_desc.band_ptr, csrc/kernels_front.hip: the blocks of
     a band are merged on the device from the factor): every cut -- pairs, triples, four heights, ragged ones, on the
     plan's numbering and on a foreign one (index map in the sweeps) -- solves the systems like one launch per height, and
-    a solve takes 2 x bands launches.  A band of five heights is refused."""
+    a solve takes 2 x bands launches (one less with the top band stored as explicit inverses, dots_front_desc.top_inverse).
+    A band of five heights is refused."""
     from dots_socp_amd import _lib
 
     geom, _ = meshes.example(mesh, **kw)
     out, launches = {}, {}
     H = None
     for tag, reorder, cuts in (("off", "nd", "unit"), ("auto", "nd", None), ("pairs", "nd", 2), ("triples", "nd", 3), ("fours", "nd", 4),
-                               ("ragged", "nd", "ragged"), ("rcm_triples", True, 3), ("host_pairs", "nd", 2)):
+                               ("ragged", "nd", "ragged"), ("rcm_triples", True, 3), ("host_pairs", "nd", 2),
+                               ("off_topinv", "nd", "unit"), ("triples_topinv", "nd", 3), ("rcm_fours_topinv", True, 4)):
         dev = make(geom, T, eps, reorder)
         if H is None:
             H = int(dev.plan.dissection.height.max()) + 1
@@ -164,9 +166,12 @@ def test_merged_tree_heights_give_the_same_solution(mesh, kw, T, eps):
             bands = None
         else:      # from the top: `cuts` heights per band, the leaves' band takes the rest
             bands = np.asarray(sorted(set(range(H, 0, -cuts)) | {0}))
-        s = dev.setup_frontal(eps=eps, bands=bands, numeric="host" if tag.startswith("host") else "device")
-        assert s["launches_per_solve"] == 2 * (len(s["bands"]) - 1)
-        assert s["bytes_per_solve_as_installed"] >= s["bytes_per_solve_one_block_per_node"] * (1.0 - 1e-12)
+        top = tag.endswith("topinv")       # the top band as explicit inverses: its forward launch writes the solution
+        s = dev.setup_frontal(eps=eps, bands=bands, numeric="host" if tag.startswith("host") else "device", top_inverse=top if bands is not None else None)
+        assert s["launches_per_solve"] == 2 * (len(s["bands"]) - 1) - (1 if s["top_inverse"] else 0)
+        assert s["top_inverse"] == top or bands is None
+        if not s["top_inverse"]:     # (an explicit inverse is read once: n^2 entries instead of n (n + 1) / 2 twice)
+            assert s["bytes_per_solve_as_installed"] >= s["bytes_per_solve_one_block_per_node"] * (1.0 - 1e-12)
         launches[tag] = s["launches_per_solve"]
         st = dev.run_phase("laplacian")
         assert st.cg_not_converged == 0
