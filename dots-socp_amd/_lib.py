@@ -121,11 +121,12 @@ def library_path() -> str:
 
 
 def _torch_runtime_first():
-    """PyTorch-ROCm wheels bundle their own HIP runtime.  When both runtimes live in one process (torch.distributed for the
-    exchanges of distributed.py, the tests' device buffers), torch must initialise its runtime BEFORE this library touches the
-    device: the other order leaves torch with "No HIP GPUs are available" (measured on MI355X / ROCm 7.2 with torch 2.10+rocm7.0).
-    If torch is already imported, initialise it here; a process that imports torch only later must call torch.cuda.init() itself
-    before it creates a context."""
+    """PyTorch-ROCm wheels bundle their own copy of the HIP runtime under the same SONAME (libamdhip64.so.7) this library
+    links against, so a process ends up with ONE runtime: whichever copy is loaded first.  Loaded after torch, this library
+    runs on torch's copy (streams, events and device pointers are then interchangeable between the two, which distributed.py
+    relies on); loaded BEFORE torch, the system copy is bound and torch's own build fails on it with "No HIP GPUs are
+    available" (measured: ROCm 7.2 system runtime, torch 2.10+rocm7.0).  If torch is already imported, initialise it here; a
+    process that imports torch only later must do that before it loads this library."""
     import sys
 
     torch = sys.modules.get("torch")

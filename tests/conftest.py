@@ -37,8 +37,8 @@ def has_gpu():
         return False
 
 
-# The GPU tests that stage exchange buffers in torch tensors need torch's (bundled) HIP runtime initialised before the
-# product library touches the device (dots-socp_amd/_lib.py: _torch_runtime_first): do it once, whatever file runs first.
+# torch's bundled HIP runtime must be the one the process binds (dots-socp_amd/_lib.py: _torch_runtime_first): load and
+# initialise torch before the product library, whatever test file runs first.
 if has_gpu():
     import torch
 
