@@ -320,6 +320,8 @@ class ShardedAlmSolver(AlmSolver):
         self._order(ctx_waits=True)
         t_comm += time.perf_counter() - t0
         stats.append(dev.slab_stage(3, wait=wait))
+        if quiet:
+            self.quiet_steps += 1
         if enqueue_only:
             self.untimed_steps += 1
             return

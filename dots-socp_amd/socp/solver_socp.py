@@ -73,7 +73,9 @@ class AlmSolver:
         self.check_kkt_step_by_step = check_kkt_step_by_step
         self.is_palm = bool(is_palm)      # an extra (q, lambda_c) solve opens every iteration (solver_socp.py:668-672)
         self.direct = direct = lap_solver == "modal_direct"
-        self.untimed_steps = 0
+        self.untimed_steps = 0          # iterations whose phases were not timed (run_history.steps_time holds the others)
+        self.quiet_steps = 0            # iterations after which nothing was read back
+        self._read_back_steps = 0
         if direct and reorder is True:
             reorder = "nd"      # the elimination order of the factor doubles as the locality numbering
         self.dev = dev = DeviceProblem(n_time, geometry, lap_solver="modal_pcg" if direct else lap_solver, device=device,
@@ -261,7 +263,17 @@ class AlmSolver:
         need not be stored, and with the direct solver the host does not wait for the device either."""
         # is_palm's step 0 reads z_mid of the previous iteration: it is stored every iteration then
         self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm)
-        if quiet and self.direct:
+        # With the direct solver an iteration needs no host round trip: it is only enqueued, and on iterations that read
+        # back the KKT kernels follow it on the stream (one wait, at the read-back).  The phase timers of the history
+        # (Step 1-1 ...: five events and a host wait per iteration) are SAMPLED: the first read-back iterations and every
+        # 16th one after them; the early iterations of a run read back every 1-3 iterations (penalty schedule,
+        # admm_tools.py:43-48) and would otherwise run at host-launch speed.
+        sample = not quiet and (self._read_back_steps < 4 or self._read_back_steps % 16 == 0)
+        if not quiet:
+            self._read_back_steps += 1
+        else:
+            self.quiet_steps += 1
+        if self.direct and not sample:
             self.dev.step(1, wait=False)
             self.untimed_steps += 1
         else:

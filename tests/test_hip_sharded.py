@@ -294,7 +294,7 @@ def test_finite_time_limit_adds_no_collectives_to_quiet_iterations():
         alm = ShardedAlmSolver(6, geom, comm=comm, nit=400, tol=1e-30, time_limit=1000)
         for _ in range(150):
             alm.iterate()
-        quiet = alm.untimed_steps
+        quiet = alm.quiet_steps
         calls = dict(comm.calls)
         clock = alm.clock_exchanges
         alm.close()
