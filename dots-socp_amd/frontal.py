@@ -196,31 +196,38 @@ def symbolic_native(diss: Dissection, indptr, indices):
 # ------------------------------------------------------------------------------------------------
 # bands of tree heights that one launch of a sweep handles (csrc/kernels_front.hip, "merged heights")
 # ------------------------------------------------------------------------------------------------
+def _band_tops_full(diss: Dissection, n, b, lo, hi):
+    """(entries of the members' rows, columns of every merged node, boundary rows of every merged node) of the band of
+    heights [lo, hi), vectorised over the nodes of one height at a time (children before parents)."""
+    h, child, parent = diss.height, diss.child, diss.parent
+    desc = np.zeros(n.size, dtype=np.int64)
+    for k in range(lo + 1, hi):
+        P = np.flatnonzero(h == k)
+        for s in range(2):
+            c = child[P, s]
+            ok = (c >= 0) & (h[np.maximum(c, 0)] >= lo)
+            cc = np.maximum(c, 0)
+            desc[P] += np.where(ok, desc[cc] + n[cc], 0)
+    inb = (h >= lo) & (h < hi)
+    entries = int((n[inb] * (n[inb] + 1) // 2 + n[inb] * desc[inb]).sum())
+    top = inb & ((parent < 0) | (h[np.maximum(parent, 0)] >= hi))
+    return entries, (desc + n)[top], b[top]
+
+
 def band_entries(diss: Dissection, node_n, node_b, lo, hi):
     """(factor entries one sweep reads, front rows, vector entries the forward workgroups read) when the heights
     [lo, hi) are merged: a member's rows hold its own triangle plus the columns of its descendants inside the band, the
     top member's boundary rows all columns; every row block of a merged node reads the right-hand side and the update
     planes of its columns (2, 4 or 8 planes for bands of 1, 2 or more heights above the leaves)."""
-    h, child, parent = diss.height, diss.child, diss.parent
     n = np.asarray(node_n, dtype=np.int64)
     b = np.asarray(node_b, dtype=np.int64)
-    inb = (h >= lo) & (h < hi)
-    desc = np.zeros(n.size, dtype=np.int64)
-    entries = rows = 0
-    tops = []
-    for p in np.flatnonzero(inb):          # ascending = children first
-        for c in child[p]:
-            if c >= 0 and inb[c]:
-                desc[p] += desc[c] + n[c]
-        entries += n[p] * (n[p] + 1) // 2 + n[p] * desc[p]
-        if parent[p] < 0 or not inb[parent[p]]:
-            entries += b[p] * (desc[p] + n[p])
-            rows += desc[p] + n[p] + b[p]
-            tops.append((int(desc[p] + n[p]), int(b[p])))
+    entries, nm, bm = _band_tops_full(diss, n, b, lo, hi)
+    entries += int((bm * nm).sum())
+    rows = int((nm + bm).sum())
     planes = 0 if lo == 0 else (2 if hi - lo == 1 else (4 if hi - lo == 2 else 8))
     rb = 4 if rows >= 4096 else (2 if rows >= 2048 else 1)
-    vec = sum((0.5 * nm * nm + nm * bm) / rb * (1 + planes) for nm, bm in tops)
-    return int(entries), int(rows), float(vec)
+    vec = float((0.5 * nm * nm + nm * bm).sum()) / rb * (1 + planes)
+    return entries, rows, vec
 
 
 # Cost model of the sweeps, fitted to the solve times of ~3 000 cuts measured on MI355X (meshes of 2.5 k to 41 k vertices,
@@ -300,17 +307,7 @@ def plan_bands(diss: Dissection, node_n, node_b, pitch, max_heights=4, spec=None
 
 def _band_tops(diss: Dissection, n, lo, hi):
     """columns of the merged nodes of the band of heights [lo, hi)"""
-    h, child, parent = diss.height, diss.child, diss.parent
-    inb = (h >= lo) & (h < hi)
-    desc = np.zeros(n.size, dtype=np.int64)
-    tops = []
-    for p in np.flatnonzero(inb):
-        for c in child[p]:
-            if c >= 0 and inb[c]:
-                desc[p] += desc[c] + n[c]
-        if parent[p] < 0 or not inb[parent[p]]:
-            tops.append(int(desc[p] + n[p]))
-    return tops
+    return [int(x) for x in _band_tops_full(diss, n, np.zeros_like(n), lo, hi)[1]]
 
 
 def sweep_order(diss: Dissection, bands):

@@ -14,8 +14,9 @@ bench.WORKLOADS["sphere2k"] = dict(example="sphere", kw=dict(level=4), n_time=31
 wl = bench.WORKLOADS[name]
 geom, _ = meshes.example(wl["example"], **wl["kw"])
 
-def run(spec):
+def run(spec, top="0"):
     os.environ["DOTS_FRONT_BANDS"] = spec
+    os.environ["DOTS_FRONT_TOPINV"] = top
     alm = AlmSolver(wl["n_time"], geom, congestion=wl["congestion"], nit=10, tol=1e-30, lap_solver="modal_direct", time_limit=float("inf"))
     for _ in range(3):
         alm.iterate()
@@ -42,15 +43,16 @@ for c in comps(H, (1, 2, 3, 4)):
         continue
     cuts = np.concatenate([[0], np.cumsum(c)])
     spec = ",".join(str(int(x)) for x in cuts)
-    try:
-        ms, _, mb, bands = run(spec)
-    except Exception as e:
-        print(spec, "failed", e, flush=True)
-        continue
-    res.append((ms, spec, mb, bands))
+    for top in ("0", "1"):
+        try:
+            ms, _, mb, bands = run(spec, top)
+        except Exception as e:
+            print(spec, top, "failed", e, flush=True)
+            continue
+        res.append((ms, spec + ("+inv" if top == "1" else ""), mb, bands))
 res.sort()
 for ms, spec, mb, bands in res[:25]:
     print(f"{ms*1e3:7.1f} us  {mb:7.0f} MB  asked {spec}  got {bands}", flush=True)
 print("worst", res[-1][:3])
 import json
-json.dump({"workload": name, "off_ms": ms0, "heights": H, "results": [(ms, spec, mb) for ms, spec, mb, _ in res]}, open(f"gpurun_out/sweep_{name}.json", "w"))
+json.dump({"workload": name, "with_top_inverse": True, "off_ms": ms0, "heights": H, "results": [(ms, spec, mb) for ms, spec, mb, _ in res]}, open(f"gpurun_out/sweep_inv_{name}.json", "w"))
