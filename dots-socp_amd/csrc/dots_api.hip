@@ -210,6 +210,8 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     if ((rc = dev_alloc(c, &c->stage, c->stage_count))) return rc;
     DOTS_HIP(hipHostMalloc((void **)&c->h_pinned, sizeof(double) * CgScalOffsets::TOTAL, hipHostMallocDefault));
     DOTS_HIP(hipHostMalloc((void **)&c->h_flags, sizeof(int) * FLAG_TOTAL, hipHostMallocDefault));
+    DOTS_HIP(hipHostMalloc((void **)&c->h_mail, sizeof(double) * (MAX_SUMS + 8), hipHostMallocCoherent | hipHostMallocMapped));
+    for (int i = 0; i < MAX_SUMS + 8; ++i) c->h_mail[i] = 0.0;
 
     // the PCG's view of the device data (see Ctx::dcg), and on a slab the global-time view of the transforms
     c->dcg = d;
@@ -402,6 +404,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
     if (const char *e = getenv("DOTS_CG_STAGE_LDS")) c->cg_stage_lds = atoi(e) != 0;
     if (const char *e = getenv("DOTS_MG_TAIL_ROWS")) c->mg_tail_rows = atoi(e);
     if (const char *e = getenv("DOTS_SOC_WITH_RHS")) c->soc_with_rhs = atoi(e) != 0;
+    if (const char *e = getenv("DOTS_SPIN_FETCH")) c->spin_fetch = atoi(e);
     if (const char *e = getenv("DOTS_FRONT_VEC2")) c->front_vec2 = atoi(e);      // 0 never, 1 where bandwidth-bound (default), 2 always
     if (const char *e = getenv("DOTS_FRONT_RB")) c->front_rb_max = std::min(4, std::max(1, atoi(e)));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -423,6 +426,7 @@ int dots_destroy(dots_ctx *c) {
     for (int i = 0; i < c->n_allocs; ++i) (void)hipFree(c->allocs[i]);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
+    if (c->h_mail) (void)hipHostFree(c->h_mail);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -253,6 +253,9 @@ struct Ctx {
     double *stage = nullptr;      // device staging buffer (largest state array)
     int64_t stage_count = 0;
     double *h_pinned = nullptr;   // pinned host scalars
+    double *h_mail = nullptr;     // coherent pinned host memory the device writes itself: [0, MAX_SUMS) sums, [MAX_SUMS] sequence number (fetch_sums)
+    uint64_t mail_seq = 0;
+    int spin_fetch = 1;           // DOTS_SPIN_FETCH=0: copy + stream synchronise instead of the device-written mailbox (A/B measurements)
     int *h_flags = nullptr;
     int n_partial_blocks = 0;
     int last_cg_iters = 0;

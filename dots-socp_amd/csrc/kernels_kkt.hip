@@ -7,6 +7,8 @@
 // the ~20 scalars are combined on the host side of the C ABI exactly as the reference's closures do.
 #include "dots_dev.h"
 
+#include <atomic>
+
 #include <cmath>
 
 namespace dots {
@@ -212,7 +214,36 @@ int reduce_partials(Ctx *c, const double *part, int n_slots, int nblk, int first
     return 0;
 }
 
+// The sums reach the host through a mailbox in coherent pinned memory that a one-wavefront kernel writes itself (values,
+// system-scope fence, sequence number); the host spins on the sequence number.  Against copy + hipStreamSynchronize this
+// saves the copy's launch and the wake-up of a blocked host thread on every iteration that reads residuals back.
+__global__ void k_mail_sums(const double *__restrict__ src, int n, double *mail, double seq) {
+    const int i = threadIdx.x;
+    if (i < n) mail[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (i == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&mail[MAX_SUMS], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 static int fetch_sums(Ctx *c, int n) {
+    if (c->spin_fetch && c->h_mail && n <= MAX_SUMS && n <= 64) {
+        const double seq = (double)(++c->mail_seq);
+        hipLaunchKernelGGL(k_mail_sums, dim3(1), dim3(64), 0, c->stream, c->d.scal + S::SUMS, n, c->h_mail, seq);
+        DOTS_HIP(hipGetLastError());
+        volatile double *flag = c->h_mail + MAX_SUMS;
+        bool got = false;
+        for (int64_t spins = 0; spins < 20000000; ++spins) {        // ~ tens of ms at most; then the blocking wait
+            if (*flag == seq) { got = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!got) DOTS_HIP(hipStreamSynchronize(c->stream));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int i = 0; i < n; ++i) c->h_pinned[i] = c->h_mail[i];
+        return 0;
+    }
     DOTS_HIP(hipMemcpyAsync(c->h_pinned, c->d.scal + S::SUMS, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     DOTS_HIP(hipStreamSynchronize(c->stream));
     return 0;
