@@ -210,6 +210,7 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     if ((rc = dev_alloc(c, &c->stage, c->stage_count))) return rc;
     DOTS_HIP(hipHostMalloc((void **)&c->h_pinned, sizeof(double) * CgScalOffsets::TOTAL, hipHostMallocDefault));
     DOTS_HIP(hipHostMalloc((void **)&c->h_flags, sizeof(int) * FLAG_TOTAL, hipHostMallocDefault));
+    if ((rc = dev_alloc(c, &c->kkt_counter, 2))) return rc;
     DOTS_HIP(hipHostMalloc((void **)&c->h_mail, sizeof(double) * (MAX_SUMS + 8), hipHostMallocCoherent | hipHostMallocMapped));
     for (int i = 0; i < MAX_SUMS + 8; ++i) c->h_mail[i] = 0.0;
 

@@ -255,6 +255,7 @@ struct Ctx {
     double *h_pinned = nullptr;   // pinned host scalars
     double *h_mail = nullptr;     // coherent pinned host memory the device writes itself: [0, MAX_SUMS) sums, [MAX_SUMS] sequence number (fetch_sums)
     uint64_t mail_seq = 0;
+    int *kkt_counter = nullptr;   // device counter of k_reduce_mail (last workgroup publishes)
     int spin_fetch = 1;           // DOTS_SPIN_FETCH=0: copy + stream synchronise instead of the device-written mailbox (A/B measurements)
     int *h_flags = nullptr;
     int n_partial_blocks = 0;

@@ -31,18 +31,18 @@ struct KktArgs {
 // One element per thread (a workgroup takes a quarter of a tile, as the cone projection does): the corner walks of
 // Comp(rho, f(q)) and Dual(alpha) are chains of dependent loads, and these kernels run on the iterations whose
 // residuals the host waits for.
-__global__ __launch_bounds__(BLOCK) void k_kkt_vertex(Dev d, KktArgs a) {
-    __shared__ double lds[N_VSUMS * 4];
+// (bid of nblk workgroups: the kernels below run it alone or beside the triangle part in one launch)
+__device__ __forceinline__ void kkt_vertex_body(const Dev &d, const KktArgs &a, int bid, int nblk, double *__restrict__ part, double *lds) {
     constexpr int SUB = TILE_ELEMS / BLOCK;
-    const int G8 = gridDim.x / SUB;
-    const int tile = xcd_tile(blockIdx.x % G8, d.n_vtiles);
+    const int G8 = nblk / SUB;
+    const int tile = xcd_tile(bid % G8, d.n_vtiles);
     double s[N_VSUMS];
 #pragma unroll
     for (int i = 0; i < N_VSUMS; ++i) s[i] = 0.0;
     const bool c0 = a.mask & 1u, c1 = a.mask & 2u, c2 = a.mask & 4u, c3 = a.mask & 8u, c4 = a.mask & 16u, c6 = a.mask & 64u;
     if (tile < d.n_vtiles) {
         const double ih = 1.0 / d.h, rho_s = a.ds * a.r;
-        for (int e = (blockIdx.x / G8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
+        for (int e = (bid / G8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
             const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
             if (v >= d.V || t >= d.nl) continue;
             const int iv = idxV(d, v, t);
@@ -114,22 +114,21 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_vertex(Dev d, KktArgs a) {
     block_sum<N_VSUMS>(s, lds);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int i = 0; i < N_VSUMS; ++i) d.partials[(int64_t)i * gridDim.x + blockIdx.x] = s[i];
+        for (int i = 0; i < N_VSUMS; ++i) part[(int64_t)i * nblk + bid] = s[i];
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_kkt_triangle(Dev d, KktArgs a, double *part) {
-    __shared__ double lds[N_FSUMS * 4];
+__device__ __forceinline__ void kkt_triangle_body(const Dev &d, const KktArgs &a, int bid, int nblk, double *__restrict__ part, double *lds) {
     constexpr int SUB = TILE_ELEMS / BLOCK;
-    const int G8 = gridDim.x / SUB;
-    const int tile = xcd_tile(blockIdx.x % G8, d.n_ftiles);
+    const int G8 = nblk / SUB;
+    const int tile = xcd_tile(bid % G8, d.n_ftiles);
     double s[N_FSUMS];
 #pragma unroll
     for (int i = 0; i < N_FSUMS; ++i) s[i] = 0.0;
     const bool c0 = a.mask & 1u, c1 = a.mask & 2u, c3 = a.mask & 8u, c5 = a.mask & 32u;
     if (tile < d.n_ftiles) {
         const double sB = a.sz * INV_SQRT3, rho_s = a.ds * a.r;
-        for (int e = (blockIdx.x / G8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
+        for (int e = (bid / G8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
             const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
             if (row >= 3 * d.F || t >= d.nl) continue;
             const int f = row / 3, c = row - 3 * f;
@@ -195,8 +194,16 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_triangle(Dev d, KktArgs a, double
     block_sum<N_FSUMS>(s, lds);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int i = 0; i < N_FSUMS; ++i) part[(int64_t)i * gridDim.x + blockIdx.x] = s[i];
+        for (int i = 0; i < N_FSUMS; ++i) part[(int64_t)i * nblk + bid] = s[i];
     }
+}
+
+// Workgroups [0, nv): the vertex sums (first: their corner walks are the longer chain), [nv, nv + nf): the triangle sums.
+// One launch for both on the iterations that read residuals back (independent sums: two latency-bound kernels overlap).
+__global__ __launch_bounds__(BLOCK) void k_kkt_sums(Dev d, KktArgs a, int nv, double *__restrict__ part_v, double *__restrict__ part_f) {
+    __shared__ double lds[(N_VSUMS > N_FSUMS ? N_VSUMS : N_FSUMS) * 4];
+    if ((int)blockIdx.x < nv) kkt_vertex_body(d, a, blockIdx.x, nv, part_v, lds);
+    else kkt_triangle_body(d, a, blockIdx.x - nv, gridDim.x - nv, part_f, lds);
 }
 
 // one workgroup per slot: scal[SUMS + first + slot] = sum_blk part[slot][blk]
@@ -228,21 +235,50 @@ __global__ void k_mail_sums(const double *__restrict__ src, int n, double *mail,
     }
 }
 
+// The reduction of the KKT sums and their hand-over in one launch: workgroup = slot (vertex slots sum nv partial blocks,
+// triangle slots nf; a part that did not run gives 0); every workgroup writes its sum to scal and to the mailbox, the last one
+// to arrive (device counter) publishes the sequence number.
+__global__ __launch_bounds__(BLOCK) void k_reduce_mail(const double *__restrict__ part_v, int nv, const double *__restrict__ part_f, int nf,
+                                                       double *__restrict__ out, double *mail, double seq, int *counter) {
+    __shared__ double lds[4];
+    const int slot = blockIdx.x;
+    const bool vs = slot < N_VSUMS;
+    const double *__restrict__ part = vs ? part_v + (int64_t)slot * nv : part_f + (int64_t)(slot - N_VSUMS) * nf;
+    const int nblk = vs ? nv : nf;
+    double v[1] = {0.0};
+    for (int g = threadIdx.x; g < nblk; g += BLOCK) v[0] += part[g];
+    block_sum<1>(v, lds);
+    if (threadIdx.x == 0) {
+        out[slot] = v[0];
+        mail[slot] = v[0];
+        __threadfence_system();
+        if (atomicAdd(counter, 1) == (int)gridDim.x - 1) {
+            *counter = 0;
+            __threadfence_system();
+            __hip_atomic_store(&mail[MAX_SUMS], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+static int wait_mail(Ctx *c, double seq, int n) {
+    volatile double *flag = c->h_mail + MAX_SUMS;
+    bool got = false;
+    for (int64_t spins = 0; spins < 20000000; ++spins) {        // ~ tens of ms at most; then the blocking wait
+        if (*flag == seq) { got = true; break; }
+        __builtin_ia32_pause();
+    }
+    if (!got) DOTS_HIP(hipStreamSynchronize(c->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i) c->h_pinned[i] = c->h_mail[i];
+    return 0;
+}
+
 static int fetch_sums(Ctx *c, int n) {
     if (c->spin_fetch && c->h_mail && n <= MAX_SUMS && n <= 64) {
         const double seq = (double)(++c->mail_seq);
         hipLaunchKernelGGL(k_mail_sums, dim3(1), dim3(64), 0, c->stream, c->d.scal + S::SUMS, n, c->h_mail, seq);
         DOTS_HIP(hipGetLastError());
-        volatile double *flag = c->h_mail + MAX_SUMS;
-        bool got = false;
-        for (int64_t spins = 0; spins < 20000000; ++spins) {        // ~ tens of ms at most; then the blocking wait
-            if (*flag == seq) { got = true; break; }
-            __builtin_ia32_pause();
-        }
-        if (!got) DOTS_HIP(hipStreamSynchronize(c->stream));
-        std::atomic_thread_fence(std::memory_order_acquire);
-        for (int i = 0; i < n; ++i) c->h_pinned[i] = c->h_mail[i];
-        return 0;
+        return wait_mail(c, seq, n);
     }
     DOTS_HIP(hipMemcpyAsync(c->h_pinned, c->d.scal + S::SUMS, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     DOTS_HIP(hipStreamSynchronize(c->stream));
@@ -259,18 +295,21 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
     const bool need_v = mask & (1u | 2u | 4u | 8u | 16u | 64u), need_f = mask & (1u | 2u | 8u | 32u);
     for (int i = 0; i < N_SUMS; ++i) sums[i] = 0.0;
     if (d.nl == 0) return 0;          // a rank without nodes contributes nothing
-    if (need_v) {
-        hipLaunchKernelGGL(k_kkt_vertex, dim3(gv), dim3(BLOCK), 0, c->stream, d, a);
-        int rc = reduce_partials(c, d.partials, N_VSUMS, gv, 0);
-        if (rc) return rc;
+    const int nv = need_v ? gv : 0, nf = need_f ? gf : 0;
+    if (nv + nf == 0) return 0;
+    hipLaunchKernelGGL(k_kkt_sums, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
+    int rc;
+    if (c->spin_fetch && c->h_mail && c->kkt_counter) {
+        const double seq = (double)(++c->mail_seq);
+        hipLaunchKernelGGL(k_reduce_mail, dim3(N_SUMS), dim3(BLOCK), 0, c->stream, d.partials, nv, part_f, nf, c->d.scal + S::SUMS, c->h_mail, seq, c->kkt_counter);
+        DOTS_HIP(hipGetLastError());
+        rc = wait_mail(c, seq, N_SUMS);
+    } else {
+        if (nv && (rc = reduce_partials(c, d.partials, N_VSUMS, nv, 0))) return rc;
+        if (nf && (rc = reduce_partials(c, part_f, N_FSUMS, nf, N_VSUMS))) return rc;
+        DOTS_HIP(hipGetLastError());
+        rc = fetch_sums(c, N_SUMS);
     }
-    if (need_f) {
-        hipLaunchKernelGGL(k_kkt_triangle, dim3(gf), dim3(BLOCK), 0, c->stream, d, a, part_f);
-        int rc = reduce_partials(c, part_f, N_FSUMS, gf, N_VSUMS);
-        if (rc) return rc;
-    }
-    DOTS_HIP(hipGetLastError());
-    int rc = fetch_sums(c, N_SUMS);
     if (rc) return rc;
     // slots of kernels that did not run hold leftovers of earlier calls: report zeros there
     for (int i = 0; i < N_SUMS; ++i) sums[i] = ((i < N_VSUMS) ? need_v : need_f) ? c->h_pinned[i] : 0.0;
