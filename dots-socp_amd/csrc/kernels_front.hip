@@ -500,7 +500,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     double entries_unmerged = 0.0;
     for (int p = 0; p < nn; ++p) {
         const int64_t n = h->node_n[p], b = h->node_b[p];
-        if (n < 0 || b < 0 || n + b < 1) return bad("node size");
+        if (n < 0 || b < 0) return bad("node size");      // (n + b = 0: the empty top separator of a mesh of several components)
         if (h->node_foff[p] != fo || h->node_ioff[p] != io || h->node_uoff[p] != uo) return bad("node offsets are not the running sums");
         for (int k = 0; k < 2; ++k) {
             const int ch = h->node_child[2 * p + k];

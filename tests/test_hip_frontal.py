@@ -186,3 +186,30 @@ def test_merged_tree_heights_give_the_same_solution(mesh, kw, T, eps):
     assert launches["off"] == 2 * H and launches["pairs"] < launches["off"] and launches["fours"] <= launches["triples"] <= launches["pairs"]
     for tag in out:
         assert rel(out[tag], out["off"]) < 1e-10, tag
+
+
+def test_two_components_and_empty_separators():
+    """A mesh of two disjoint spheres: the dissection's first cut falls between the components (an empty separator whose node
+    only passes updates on), the operator is regular with eps > 0: merged bands and the top inverse solve it like the PCG."""
+    a, _ = meshes.example("sphere", level=3)
+    va, ta = np.asarray(a["vertices"]), np.asarray(a["triangles"])
+    v = np.concatenate([va, va * 0.7 + np.array([3.0, 0.2, -0.1])])
+    t = np.concatenate([ta, ta + va.shape[0]])
+    mu0 = np.concatenate([a["mu0"], a["mu0"][::-1]])
+    mu1 = np.concatenate([a["mu1"], a["mu1"][::-1]])
+    geom = dict(vertices=v, triangles=t, mu0=mu0 / mu0.sum(), mu1=mu1 / mu1.sum())
+    out = {}
+    for tag in ("direct", "direct_off", "pcg"):
+        dev = make(geom, 15, 1e-2, "nd" if tag != "pcg" else True)
+        if tag == "pcg":
+            assert dev.setup_multigrid(eps=1e-2) is not None
+        else:
+            H = int(dev.plan.dissection.height.max()) + 1
+            s = dev.setup_frontal(eps=1e-2, bands=None if tag == "direct" else np.arange(H + 1))
+            assert s["empty_separators"] >= 1
+        st = dev.run_phase("laplacian")
+        assert st.cg_not_converged == 0
+        out[tag] = dev.download("phi")
+        dev.close()
+    assert rel(out["direct"], out["direct_off"]) < 1e-10
+    assert rel(out["direct"], out["pcg"]) < 1e-8
