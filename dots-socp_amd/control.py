@@ -185,11 +185,18 @@ class AdaptiveValidator:
         self.iteration_counter = 0
 
     def set_error_and_tolerance(self, error, tolerance):
-        ratio = float(np.max(np.atleast_1d(error) / np.maximum(np.atleast_1d(tolerance), 1e-10)))
-        if ratio <= 1.0:
-            self.current_interval = self.min_interval
-            return
-        log_ratio = np.log10(ratio)
+        if isinstance(error, float) and isinstance(tolerance, float):      # the solver's call: plain floats, no numpy round trips
+            ratio = error / max(tolerance, 1e-10)
+            if ratio <= 1.0:
+                self.current_interval = self.min_interval
+                return
+            log_ratio = math.log10(ratio) if ratio == ratio and ratio != math.inf else ratio      # nan, inf pass through as in numpy
+        else:
+            ratio = float(np.max(np.atleast_1d(error) / np.maximum(np.atleast_1d(tolerance), 1e-10)))
+            if ratio <= 1.0:
+                self.current_interval = self.min_interval
+                return
+            log_ratio = np.log10(ratio)
         if log_ratio > 1.0:
             self.current_interval = self.max_interval
         else:
