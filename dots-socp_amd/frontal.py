@@ -239,6 +239,7 @@ BAND_LAUNCH_US = (3.7, 8.0)     # small factors ... factors of 1 GB and more (mo
 BAND_FACTOR_TBS = ((1.0e8, 7.3), (3.0e8, 5.3), (1.0e9, 4.5), (3.0e9, 3.0))      # (factor bytes read per solve, TB/s)
 BAND_STEP_US = 0.45
 BAND_VECTOR_TBS = 67.0          # right-hand side and update planes re-read by every row block (L2)
+BAND_INVERSE_MAX_COLS = 450     # an explicit top inverse pays up to about this many columns per node (knot 398: -5 us; sphere10k 559: +14 us)
 
 
 def _factor_tbs(total):
@@ -289,7 +290,7 @@ def plan_bands(diss: Dissection, node_n, node_b, pitch, max_heights=4, spec=None
             steps = max(tops) / 32.0
             cost[(lo, hi)] = launch_us + e * unit / (factor_tbs * 1e6) + (vec + 3.0 * rows) * unit / (BAND_VECTOR_TBS * 1e6) * big \
                 + 0.75 * steps * BAND_STEP_US
-            if hi == H and top_spec != "0":       # per sweep: half of ONE launch that reads n^2 entries per node, in full rows
+            if hi == H and top_spec != "0" and (max(tops) <= BAND_INVERSE_MAX_COLS or top_spec == "1"):       # per sweep: half of ONE launch that reads n^2 entries per node, in full rows
                 full = float(sum(t * t for t in tops))
                 inv_cost[lo] = 0.5 * (launch_us + full * unit / (factor_tbs * 1e6) + steps * BAND_STEP_US)
     best = {0: (0.0, [0], False)}
