@@ -129,3 +129,35 @@ def test_merged_heights_solve_the_same_systems(name, kw, cuts):
     assert np.max(np.abs(x1 - x0)) < 1e-10 * np.max(np.abs(x0))
     x2 = frontal_cpu.solve_merged(ff, bands, b, top_inverse=True)      # the top band as one explicit inverse
     assert np.max(np.abs(x2 - x0)) < 1e-10 * np.max(np.abs(x0))
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+def test_band_planner(name, kw, monkeypatch):
+    """frontal.plan_bands: valid cuts for every specification, the same answer on every call (the ranks of a sharded run
+    must cut alike), and the numbering of the plan is the order in which the merged sweeps walk the vertices."""
+    plan, K = problem(name, "nd", **kw)
+    d = plan.dissection
+    H = int(d.height.max()) + 1
+    n = np.diff(d.sep_ptr)
+    b = frontal.symbolic_native(d, K.indptr, K.indices)[0]
+    for spec in ("auto", "off", ",".join(str(x) for x in sorted(set(range(0, H, 2)) | {H}))):
+        for top in ("auto", "0", "1"):
+            cuts, inv = frontal.plan_bands(d, n, b, 8, spec=spec, top_spec=top)
+            assert cuts[0] == 0 and cuts[-1] == H and np.all(np.diff(cuts) >= 1) and np.all(np.diff(cuts) <= 4)
+            assert (top != "0" or not inv) and (top != "1" or inv or spec == "auto")
+            again = frontal.plan_bands(d, n, b, 8, spec=spec, top_spec=top)
+            assert np.array_equal(cuts, again[0]) and inv == again[1]
+    with pytest.raises(ValueError):
+        frontal.plan_bands(d, n, b, 8, spec="0,1")                  # does not reach the last height
+    # what one sweep reads: merging never reads fewer factor entries than one launch per height, and a band of one height
+    # reads exactly its nodes' blocks
+    e_unit = sum(frontal.band_entries(d, n, b, l, l + 1)[0] for l in range(H))
+    assert e_unit == int((n.astype(np.int64) * (n + 1) // 2 + b.astype(np.int64) * n).sum())
+    for lo in range(0, H - 1):
+        hi = min(H, lo + 3)
+        assert frontal.band_entries(d, n, b, lo, hi)[0] >= sum(frontal.band_entries(d, n, b, l, l + 1)[0] for l in range(lo, hi)) - \
+            sum(int(b[p]) * int(n[p]) for p in np.flatnonzero((d.height >= lo) & (d.height < hi)))
+    monkeypatch.setenv("DOTS_FRONT_BANDS", "off")
+    plan_off, _ = problem(name, "nd", **kw)
+    assert np.array_equal(plan_off.dissection.order, np.arange(plan.n_vertices))      # one launch per height: the elimination order
+    assert np.array_equal(frontal.sweep_order(d, d.bands), np.arange(plan.n_vertices))

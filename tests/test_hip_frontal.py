@@ -172,6 +172,17 @@ def test_merged_tree_heights_give_the_same_solution(mesh, kw, T, eps):
         assert s["top_inverse"] == top or bands is None
         if not s["top_inverse"]:     # (an explicit inverse is read once: n^2 entries instead of n (n + 1) / 2 twice)
             assert s["bytes_per_solve_as_installed"] >= s["bytes_per_solve_one_block_per_node"] * (1.0 - 1e-12)
+            if reorder == "nd":      # the planner's count of what the merged sweeps read = the device's own
+                import scipy.sparse as sp
+
+                from dots_socp_amd import frontal
+
+                p_, d_ = dev.plan, dev.plan.dissection
+                K_ = sp.csr_matrix((p_.lap_val, p_.lap_col, p_.lap_rowptr), shape=(p_.n_vertices,) * 2)
+                nb_ = frontal.symbolic_native(d_, K_.indptr, K_.indices)[0]
+                n_ = np.diff(d_.sep_ptr)
+                e_ = sum(frontal.band_entries(d_, n_, nb_, int(lo), int(hi))[0] for lo, hi in zip(s["bands"][:-1], s["bands"][1:]))
+                assert s["bytes_per_solve_as_installed"] == 2.0 * e_ * (T + 1) * 8
         launches[tag] = s["launches_per_solve"]
         st = dev.run_phase("laplacian")
         assert st.cg_not_converged == 0
