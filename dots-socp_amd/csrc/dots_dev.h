@@ -115,15 +115,12 @@ struct MgDev {
 // Direct (multifrontal) solve of the modal problems: the factor of dots-socp_amd/frontal.py on the device.
 // F_p = [L_pp^-1 ; A_bs A_ss^-1] of node p starts at F + (foff[p] << tp_shift), entry (i, j, mode) at
 // ((i * n_p + j) << tp_shift) + mode: the mode index is fastest, as in every node array.
-struct FrontNode {
+struct FrontNode {            // a node of the elimination tree as the numeric factorisation sees it (kernels_factor.hip)
     int n, b;                 // separator rows eliminated here / boundary rows
     int k0;                   // elimination index of the first separator row
-    int has_children;
+    int parent;               // parent node (-1: root)
     int64_t foff;             // first (row, col) entry of F_p
-    int64_t woff;             // first row of this node's two update planes in W (plane k: child k), m rows each
-    int64_t parent_w;         // first row of the plane this node writes in its parent's W (-1: root)
-    int64_t bdoff;            // first boundary row of this node in bd_vertex / cmap
-    // used by the numeric factorisation only (kernels_factor.hip)
+    int64_t bdoff;            // first boundary row of this node in bd_vertex
     int c0, c1;               // children (-1: none)
     int64_t ioff;             // first front row in the pull maps
     int64_t soff;             // first entry of the b x b Schur complement

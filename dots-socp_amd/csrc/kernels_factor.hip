@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_fact_assemble(FactArgs g, FrontDev f) {
     const int n = nd.n, b = nd.b, m = n + b;
     const int64_t nC = (int64_t)m * n, total = nC + (int64_t)b * b;
     const double shift = g.sigma[a] + g.eps;
-    const bool ground = nd.parent_w < 0 && g.grounded[a];
+    const bool ground = nd.parent < 0 && g.grounded[a];
     const FrontNode c0 = nd.c0 >= 0 ? f.nodes[nd.c0] : nd;
     const FrontNode c1 = nd.c1 >= 0 ? f.nodes[nd.c1] : nd;
     for (int64_t e = (int64_t)blockIdx.x * Q + q; e < total; e += (int64_t)gridDim.x * Q) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_fact_linv(FactArgs g, FrontDev f) {
     if (j >= n || a >= g.ncol) return;
     const double *__restrict__ L = g.C + (nd.foff << sh) + a;
     double *__restrict__ X = g.T + (nd.foff << sh) + a;
-    const bool ground = nd.parent_w < 0 && g.grounded[a];
+    const bool ground = nd.parent < 0 && g.grounded[a];
     for (int i = j; i < n; ++i) {
         const double *__restrict__ Li = L + (((int64_t)i * n) << sh);
         double s0 = (i == j) ? 1.0 : 0.0, s1 = 0.0;

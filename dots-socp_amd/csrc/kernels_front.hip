@@ -571,14 +571,12 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             nd.k0 = k0;
             nd.foff = h->node_foff[p];
             nd.bdoff = h->node_uoff[p];
-            nd.parent_w = parent[p];        // the factorisation only asks "< 0: root"
+            nd.parent = parent[p];
             nd.c0 = h->node_child[2 * p];
             nd.c1 = h->node_child[2 * p + 1];
             nd.ioff = h->node_ioff[p];
             nd.soff = soff;
             soff += (int64_t)nd.b * nd.b;
-            nd.has_children = (nd.c0 >= 0 || nd.c1 >= 0) ? 1 : 0;
-            nd.woff = 0;
             const int64_t io2 = h->node_ioff[p];
             for (int i = 0; i < nd.n; ++i) {
                 const int v = h->front_idx[io2 + i];
