@@ -419,6 +419,137 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
     }
 }
 
+// The same kernel with TWO consecutive nodes (t, t + 1; t even) per lane: every array of the triangle part is read and written in
+// the column of the node (idxM), so both nodes of a lane sit in one aligned 16-byte word of every row; the mesh constants of
+// (f, c) are loaded once for both.  Half the waves for the same bytes: these launches are latency-bound at full occupancy on
+// the small meshes (time ~ waves x chain / resident waves).  Element for element the arithmetic of k_q_lambda_mult_triangle.
+struct D2 { double v[2]; };
+__device__ __forceinline__ D2 ld2(const double *p) { const double2 t = *reinterpret_cast<const double2 *>(p); return D2{{t.x, t.y}}; }
+__device__ __forceinline__ void st2(double *p, const D2 &x) { *reinterpret_cast<double2 *>(p) = make_double2(x.v[0], x.v[1]); }
+template <int ZMODE, bool QONLY = false>
+__global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle2(Dev d, double sz, double tau, int nf8, double cd, double cr) {
+    constexpr int SUB = TILE_ELEMS / (2 * BLOCK);     // two elements per thread: a workgroup takes half of a triangle tile
+    if ((int)blockIdx.x >= nf8 * SUB) {
+        const int vt = xcd_tile(blockIdx.x - nf8 * SUB, d.n_vtiles);
+        if (vt < d.n_vtiles) q_lambda_vertex_tile<QONLY>(d, vt, sz, cd, cr, tau);
+        return;
+    }
+    const int tile = xcd_tile(blockIdx.x % nf8, d.n_ftiles);
+    if (tile >= d.n_ftiles) return;
+    const int row0 = tile * d.FT;
+    const double sB = sz * INV_SQRT3;
+    const double diag_in = 1.0 + 2.0 * sz * sz, diag_bd = 1.0 + sz * sz;
+    const int e = ((blockIdx.x / nf8) * BLOCK + threadIdx.x) * 2;          // first of the lane's two elements in the tile
+    const int row = row0 + (e >> d.tp_shift), t = e & (d.TP - 1);
+    if (row >= 3 * d.F || t >= d.nl) return;
+    const int f = row / 3, c = row - 3 * f;
+    const bool two = t + 1 < d.nl;                  // the second node exists (always, unless the slab holds an odd number of nodes)
+    const int64_t ie = idxF(d, f, c, t);
+    int vk[3];
+    double hk[3], Dk[3];
+    D2 phik[3], l0[3], b0[3], b1[3], z0[3], z1[3];
+    double lm1[3];                                  // the multiplier of interval t - 1 (that of interval t is l0[.].v[0])
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        vk[k] = d.tri[f * 3 + k];
+        hk[k] = d.hat[(f * 3 + k) * 3 + c];
+        Dk[k] = ZMODE ? d.fk_D[f * 3 + k] : 1.0;
+    }
+    const bool has1_0 = has_prev_interval(d, t);
+    D2 Bold = {{0.0, 0.0}};
+    if (ZMODE) Bold = ld2(d.B + ie);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        phik[k] = ld2(d.phi + idxV(d, vk[k], t));
+        b0[k] = ld2(d.bm + idxM(d, f * 3 + k, 0, c, t));
+        b1[k] = ld2(d.bm + idxM(d, f * 3 + k, 1, c, t - 1));
+        if (ZMODE) {
+            l0[k] = ld2(d.lamc + idxV(d, vk[k], t));
+            const double *pl = t > 0 ? d.lamc + idxV(d, vk[k], t - 1) : (has1_0 ? d.lamc_lo + vk[k] : d.lamc + idxV(d, vk[k], t));
+            lm1[k] = *pl;
+        } else {
+            z0[k] = ld2(d.zm + idxM(d, f * 3 + k, 0, c, t));
+            z1[k] = ld2(d.zm + idxM(d, f * 3 + k, 1, c, t - 1));
+        }
+    }
+    const D2 Eo = ld2(d.E + ie);
+    D2 Bn, En, n0[3], n1[3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int tu = t + u;
+        const bool has0 = tu < d.ni, has1 = has_prev_interval(d, tu);
+        double gx = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gx += hk[k] * phik[k].v[u];
+        double S = 0.0;
+        const double sBold = sB * Bold.v[u];
+        double zz0[3], zz1[3], bb0[3], bb1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bb0[k] = b0[k].v[u];
+            bb1[k] = b1[k].v[u];
+            if (ZMODE) {
+                const double l1 = u == 0 ? lm1[k] : l0[k].v[0];
+                zz0[k] = (l0[k].v[u] / Dk[k]) * (Dk[k] * (sBold - bb0[k]));
+                zz1[k] = (l1 / Dk[k]) * (Dk[k] * (sBold - bb1[k]));
+            } else {
+                zz0[k] = z0[k].v[u];
+                zz1[k] = z1[k].v[u];
+            }
+            if (!has0) zz0[k] = bb0[k] = 0.0;
+            if (!has1) zz1[k] = bb1[k] = 0.0;
+            z0[k].v[u] = zz0[k];
+            z1[k].v[u] = zz1[k];
+            S += (zz0[k] + bb0[k]) + (zz1[k] + bb1[k]);
+        }
+        const double bn = (gx + Eo.v[u] + sB * S) / ((first_node(d, tu) || last_node(d, tu)) ? diag_bd : diag_in);
+        Bn.v[u] = bn;
+        En.v[u] = Eo.v[u] + tau * (gx - bn);
+        const double sBn = sB * bn;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            // slots whose interval does not exist keep what they hold (zeros): the scalar kernel does not store them either
+            n0[k].v[u] = has0 ? bb0[k] + tau * (zz0[k] - sBn) : b0[k].v[u];
+            n1[k].v[u] = has1 ? bb1[k] + tau * (zz1[k] - sBn) : b1[k].v[u];
+        }
+    }
+    if (two) {
+        if (ZMODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // (entries of intervals that do not exist are stored as the zeros computed above; their slots are never read as data)
+                st2(d.zm + idxM(d, f * 3 + k, 0, c, t), z0[k]);
+                st2(d.zm + idxM(d, f * 3 + k, 1, c, t - 1), z1[k]);
+            }
+        }
+        st2(d.B + ie, Bn);
+        if (QONLY) return;
+        st2(d.E + ie, En);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            st2(d.bm + idxM(d, f * 3 + k, 0, c, t), n0[k]);
+            st2(d.bm + idxM(d, f * 3 + k, 1, c, t - 1), n1[k]);
+        }
+    } else {      // only the first node of the pair exists: element-wise stores
+        const bool has0 = t < d.ni, has1 = has1_0;
+        if (ZMODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (has0) d.zm[idxM(d, f * 3 + k, 0, c, t)] = z0[k].v[0];
+                if (has1) d.zm[idxM(d, f * 3 + k, 1, c, t - 1)] = z1[k].v[0];
+            }
+        }
+        d.B[ie] = Bn.v[0];
+        if (QONLY) return;
+        d.E[ie] = En.v[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (has0) d.bm[idxM(d, f * 3 + k, 0, c, t)] = n0[k].v[0];
+            if (has1) d.bm[idxM(d, f * 3 + k, 1, c, t - 1)] = n1[k].v[0];
+        }
+    }
+}
+
 // Step 0 of is_palm = True: (A, B, lambda_c) from the current multipliers and the stored z_mid; nothing else moves.
 int launch_q_lambda_only(Ctx *c) {
     const dots_params &p = c->prm;
@@ -432,8 +563,16 @@ int launch_q_lambda_only(Ctx *c) {
 int launch_q_lambda_mult(Ctx *c, int zmid_mode) {
     const dots_params &p = c->prm;
     const int nf8 = xcd_grid(c->d.n_ftiles), nv8 = xcd_grid(c->d.n_vtiles);
-    const dim3 gf(nf8 * (TILE_ELEMS / BLOCK) + nv8);
     const double cd = p.const_d, cr = p.congestion * p.r;
+    if (c->ql_two && c->d.TP >= 4) {      // two nodes per lane (16-byte accesses): k_q_lambda_mult_triangle2
+        const dim3 g2(nf8 * (TILE_ELEMS / (2 * BLOCK)) + nv8);
+        if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_triangle2<2>), g2, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
+        else if (zmid_mode == 1) hipLaunchKernelGGL((k_q_lambda_mult_triangle2<1>), g2, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
+        else hipLaunchKernelGGL((k_q_lambda_mult_triangle2<0>), g2, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
+        DOTS_HIP(hipGetLastError());
+        return 0;
+    }
+    const dim3 gf(nf8 * (TILE_ELEMS / BLOCK) + nv8);
     if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_triangle<2>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
     else if (zmid_mode == 1) hipLaunchKernelGGL((k_q_lambda_mult_triangle<1>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
     else hipLaunchKernelGGL((k_q_lambda_mult_triangle<0>), gf, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
