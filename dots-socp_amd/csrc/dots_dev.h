@@ -264,6 +264,7 @@ struct Ctx {
     int cg_graph_mg = -1;
     int soc_with_rhs = 1;         // DOTS_SOC_WITH_RHS=0: keep the projection after the solve (A/B measurements)
     int ql_two = 1;               // steps 2+3 with two nodes per lane (DOTS_QL_TWO=0: one, for A/B measurements)
+    int rhs_two = 1;              // right-hand side + projection with two time columns per lane (DOTS_RHS_TWO=0: one)
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
     int step_palm = 0;            // dots_step_flags: every iteration opens with the (q, lambda_c) closed form (is_palm = True)
     int zmid_stale = 0;           // z_mid does not belong to the current iterate

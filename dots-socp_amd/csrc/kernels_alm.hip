@@ -23,6 +23,11 @@ namespace dots {
 // The squared norm is accumulated in two halves, s = 0 (entries of node t) and s = 1 (entries of node t + 1), each over
 // the corner list in order: when node t + 1 belongs to the next time slab that rank forms the s = 1 half from its own
 // B and beta_mid (soc_half_of_first_node) and this one reads it from the halo -- bit for bit the same sum.
+// two consecutive time columns of a row (16-byte aligned: even column, pitch a power of two)
+struct D2 { double v[2]; };
+__device__ __forceinline__ D2 ld2(const double *p) { const double2 t = *reinterpret_cast<const double2 *>(p); return D2{{t.x, t.y}}; }
+__device__ __forceinline__ void st2(double *p, const D2 &x) { *reinterpret_cast<double2 *>(p) = make_double2(x.v[0], x.v[1]); }
+
 __device__ __forceinline__ double soc_half(const Dev &d, int v, int t, int s, double sB) {
     double acc = 0.0;
     for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
@@ -88,6 +93,76 @@ __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double s
                 const double w = D * (sB * d.B[idxF(d, f, c, t + s)] - d.bm[idxM(d, fk, s, c, t)]);
                 d.zm[idxM(d, fk, s, c, t)] = lt * w;
             }
+    }
+}
+
+// The projection of the intervals t and t + 1 (t even) of a vertex by ONE lane, multiplier only (one GPU: every node is held
+// here): B and the s = 0 entries of both intervals sit in one aligned 16-byte word per row, 15 loads per corner instead of 24;
+// half the waves for the same bytes (see k_q_lambda_mult_triangle2).  Interval for interval the arithmetic of soc_element.
+__device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double sz, double cd) {
+    const double sB = sz * INV_SQRT3;
+    const int iv = idxV(d, v, t);
+    const bool two = t + 1 < d.ni;                 // the second interval exists (T odd: not for the last pair)
+    const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
+    double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
+    for (int j = j0; j < j1; ++j) {
+        const int fk = d.cidx[j];
+        const int f = fk / 3;
+        const double D = d.c_D[j];
+        D2 bt[3], m0[3];
+        double b2[3], m1a[3], m1b[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            bt[c] = ld2(d.B + idxF(d, f, c, t));
+            m0[c] = ld2(d.bm + idxM(d, fk, 0, c, t));
+            m1a[c] = d.bm[idxM(d, fk, 1, c, t)];
+            b2[c] = two ? d.B[idxF(d, f, c, t + 2)] : 0.0;
+            m1b[c] = two ? d.bm[idxM(d, fk, 1, c, t + 1)] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double w = D * (sB * bt[c].v[0] - m0[c].v[0]);
+            a0[0] += w * w;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double w = D * (sB * bt[c].v[1] - m1a[c]);
+            a1[0] += w * w;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double w = D * (sB * bt[c].v[1] - m0[c].v[1]);
+            a0[1] += w * w;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double w = D * (sB * b2[c] - m1b[c]);
+            a1[1] += w * w;
+        }
+    }
+    const D2 A = ld2(d.A + iv), bf = ld2(d.bf + iv), be = ld2(d.be + iv);
+    D2 zf, ze, lm;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const double acc = a0[u] + a1[u];
+        const double a = A.v[u];
+        const double w_fst = cd - sz * a - bf.v[u];
+        const double w_end = cd + sz * a - be.v[u];
+        const double nrm = sqrt(acc + w_end * w_end);
+        double lam = 0.5 * (1.0 + w_fst / nrm);          // 0/0 -> NaN when the pre-image is 0, as in the reference (:1018)
+        if (lam == lam) lam = fmin(fmax(lam, 0.0), 1.0);  // np.clip keeps NaN; fmin/fmax would drop it
+        zf.v[u] = (lam >= 1.0) ? w_fst : lam * nrm;
+        ze.v[u] = lam * w_end;
+        lm.v[u] = lam;
+    }
+    if (two) {
+        st2(d.zf + iv, zf);
+        st2(d.ze + iv, ze);
+        st2(d.lamc + iv, lm);
+    } else {
+        d.zf[iv] = zf.v[0];
+        d.ze[iv] = ze.v[0];
+        d.lamc[iv] = lm.v[0];
     }
 }
 
@@ -259,6 +334,74 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double ep
     modes_from_tile<true, RHS_NB>(d, d.Q, xs, Qs, IC, v0, bhat, -1, 0, 1 << 30, true);
 }
 
+// The right-hand side at the nodes t and t + 1 (t even) of a vertex by one lane (one GPU), node for node the arithmetic of
+// rhs_value: B and E of both nodes in one 16-byte word per row.
+__device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r, double eps, double (&out)[2]) {
+    const int iv = idxV(d, v, t);
+    const double m = d.mass_v[v];
+    const double ih = 1.0 / d.h;
+    const D2 A = ld2(d.A + iv), L = ld2(d.lam + iv), M = ld2(d.mu + iv), P = ld2(d.phi + iv);
+    const double xp = t > 0 ? (d.A[iv - 1] + d.lam[iv - 1] - d.mu[iv - 1]) * m : 0.0;      // interval t - 1
+    const double x0 = t < d.ni ? (A.v[0] + L.v[0] - M.v[0]) * m : 0.0;                      // interval t
+    const double x1 = t + 1 < d.ni ? (A.v[1] + L.v[1] - M.v[1]) * m : 0.0;                  // interval t + 1
+    double rhs[2] = {(x0 - xp) * ih, (x1 - x0) * ih};
+    double ds[2] = {0.0, 0.0};
+    for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+        const int f = d.cidx[j] / 3;
+        D2 b[3], e[3];
+        double ga[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t i = idxF(d, f, c, t);
+            ga[c] = d.c_gA[j * 3 + c];
+            b[c] = ld2(d.B + i);
+            e[c] = ld2(d.E + i);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ds[0] += ga[c] * (b[c].v[0] - e[c].v[0]);
+            ds[1] += ga[c] * (b[c].v[1] - e[c].v[1]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        rhs[u] -= ds[u];
+        if (t + u == 0) rhs[u] += d.mu0[v] / (r * d.h);
+        if (t + u == d.T) rhs[u] -= d.mu1[v] / (r * d.h);
+        rhs[u] -= eps * m * P.v[u];
+        out[u] = -rhs[u];
+    }
+}
+
+// k_rhs_modes with two time columns per lane (one GPU, direct solver): 512 threads per tile.
+constexpr int RHS_NB2 = RHS_NB / 2;
+__global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double eps, double *__restrict__ bhat, int IC, int n_rhs, double sz, double cd) {
+    const int e = 2 * threadIdx.x, vl = e >> d.tp_shift, t = e & (d.TP - 1);
+    if ((int)blockIdx.x >= n_rhs) {
+        const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
+        if (st >= d.n_vtiles) return;
+        const int v = st * d.VT + vl;
+        if (v < d.V && t < d.ni) soc_element2(d, v, t, sz, cd);
+        return;
+    }
+    extern __shared__ double tm_lds[];
+    const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
+    double *Qs = tm_lds;                 // [IC][TP]
+    double *xs = tm_lds + IC * TP;       // [VT][TPp]
+    const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
+    if (tile >= d.n_vtiles) return;
+    const int v0 = tile * d.VT;
+    stage_q_chunk<true, RHS_NB2>(d, d.Q, Qs, 0, min(IC, n));      // in flight while the corner walks run
+    for (int ee = e; ee < TILE_ELEMS; ee += 2 * RHS_NB2) {       // (one pass: TILE_ELEMS = 2 * RHS_NB2)
+        const int vv = ee >> d.tp_shift, tt = ee & (TP - 1);
+        double b[2] = {0.0, 0.0};
+        if (v0 + vv < d.V && tt < n) rhs_value2(d, v0 + vv, tt, r, eps, b);
+        xs[vv * TPp + tt] = b[0];
+        xs[vv * TPp + tt + 1] = tt + 1 < n ? b[1] : 0.0;
+    }
+    modes_from_tile<true, RHS_NB2>(d, d.Q, xs, Qs, IC, v0, bhat, -1, 0, 1 << 30, true);
+}
+
 // T + 1 >= 64: 32 vertices per workgroup, the transform on the matrix cores.
 __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, double eps, double *__restrict__ bhat, int n_rhs, double sz, double cd) {
     if ((int)blockIdx.x >= n_rhs) {      // riders: the cone projection of a tile, as in k_rhs_modes
@@ -281,11 +424,14 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, doub
 
 int launch_rhs(Ctx *c, bool with_soc) {
     const int g = xcd_grid(c->d.n_vtiles);
-    if (rhs_writes_modes(c) && time_modes_mfma_ok(c->d)) {
+    if (rhs_writes_modes(c) && time_modes_mfma_ok(c->d)) {      // (two time columns per lane measured here too: knot63 -1.5 %, torus65k_T127 +1.5 %: not kept)
         const int n_rhs = (c->d.V + TM_ROWS - 1) / TM_ROWS;
         hipLaunchKernelGGL(k_rhs_modes_mfma, dim3(n_rhs + (with_soc ? g : 0)), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
                            c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, c->prm.scale_z, c->prm.const_d);
     }
+    else if (rhs_writes_modes(c) && c->rhs_two && c->d.TP >= 4)      // two time columns per lane (16-byte accesses)
+        hipLaunchKernelGGL(k_rhs_modes2, dim3(with_soc ? 2 * g : g), dim3(RHS_NB2), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
+                           c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d);
     else if (rhs_writes_modes(c))
         hipLaunchKernelGGL(k_rhs_modes, dim3(with_soc ? 2 * g : g), dim3(RHS_NB), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
                            c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d);
@@ -423,9 +569,6 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
 // the column of the node (idxM), so both nodes of a lane sit in one aligned 16-byte word of every row; the mesh constants of
 // (f, c) are loaded once for both.  Half the waves for the same bytes: these launches are latency-bound at full occupancy on
 // the small meshes (time ~ waves x chain / resident waves).  Element for element the arithmetic of k_q_lambda_mult_triangle.
-struct D2 { double v[2]; };
-__device__ __forceinline__ D2 ld2(const double *p) { const double2 t = *reinterpret_cast<const double2 *>(p); return D2{{t.x, t.y}}; }
-__device__ __forceinline__ void st2(double *p, const D2 &x) { *reinterpret_cast<double2 *>(p) = make_double2(x.v[0], x.v[1]); }
 template <int ZMODE, bool QONLY = false>
 __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle2(Dev d, double sz, double tau, int nf8, double cd, double cr) {
     constexpr int SUB = TILE_ELEMS / (2 * BLOCK);     // two elements per thread: a workgroup takes half of a triangle tile
