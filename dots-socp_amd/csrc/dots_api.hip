@@ -408,7 +408,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
     if (const char *e = getenv("DOTS_QL_TWO")) c->ql_two = atoi(e);
     if (const char *e = getenv("DOTS_RHS_TWO")) c->rhs_two = atoi(e);
     if (const char *e = getenv("DOTS_SPIN_FETCH")) c->spin_fetch = atoi(e);
-    if (const char *e = getenv("DOTS_FRONT_VEC2")) c->front_vec2 = atoi(e);      // 0 never, 1 where bandwidth-bound (default), 2 always
+    if (const char *e = getenv("DOTS_FRONT_VEC2")) c->front_vec2 = atoi(e);      // 0 never, 1 / 2 wherever the pitch allows (default), 3 only where bandwidth-bound
     if (const char *e = getenv("DOTS_FRONT_RB")) c->front_rb_max = std::min(4, std::max(1, atoi(e)));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }

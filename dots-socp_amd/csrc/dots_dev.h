@@ -274,7 +274,7 @@ struct Ctx {
     int front_fwd_rb[65]{}, front_bwd_cb[65]{};     // rows / columns per workgroup on each level
     int front_fwd_nb[65]{}, front_bwd_nb[65]{};     // threads per workgroup on each level (256, or 1024 where a level has few rows)
     int front_planes[65]{};       // update planes the forward launch of a band reads per node (0, 2, 4 or 8)
-    int front_vec2 = 1;           // two modes per lane in the sweeps (DOTS_FRONT_VEC2: 0 never, 1 where bandwidth-bound, 2 always)
+    int front_vec2 = 1;           // two modes per lane in the sweeps (DOTS_FRONT_VEC2: 0 never, 1 / 2 wherever the pitch allows, 3 only where bandwidth-bound)
     int front_rb_max = 4;         // most rows (columns) of a node per workgroup (DOTS_FRONT_RB: 1, 2 or 4, for A/B measurements)
     double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps, merged blocks as stored)
     double front_bytes_unmerged = 0.0;   // the same for one launch per tree height (no merged bands)

@@ -410,11 +410,13 @@ __global__ __launch_bounds__(256) void k_top_inverse(TopInvArgs g) {
     }
 }
 
-// two modes per lane (16-byte loads): pays where the sweeps are bandwidth-bound (measured: +6 % at torus100k, +13 % at
-// T = 127; -2 % on the latency-bound sphere10k, where it is left off)
+// two modes per lane (16-byte loads, half the waves).  Round 1 (one launch per tree height): +6 % at torus100k, +13 % at T = 127,
+// -2 % on the latency-bound sphere10k; with merged bands it pays there too (knot solve 53.6 -> 51.9 us, sphere10k 97 -> 95.5 us):
+// on wherever the pitch allows.  DOTS_FRONT_VEC2=0 turns it off, =3 restores the round-1 rule (pitch >= 64 or a factor > 1 GB).
 static bool front_two_modes(const Ctx *c) {
     const Dev &d = c->dcg;
-    return c->front_vec2 && d.TP >= 4 && d.TP <= 128 && (c->front_vec2 > 1 || d.TP >= 64 || c->front_bytes > 1.0e9);
+    if (!c->front_vec2 || d.TP < 4 || d.TP > 128) return false;
+    return c->front_vec2 != 3 || d.TP >= 64 || c->front_bytes > 1.0e9;
 }
 
 // one band of the forward sweep: n workgroups of nbt threads, blk rows each, kp update planes per node
@@ -882,6 +884,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     // workgroups, so that the long dot products are split 4x finer.  Forward bands whose nodes read 4 or 8 update planes take
     // 4 rows per workgroup earlier (the planes are read once per workgroup, not per row).
     std::vector<int64_t> band_rows((size_t)nb, 0), band_cols((size_t)nb, 0);
+    const bool two_modes = front_two_modes(c);
     for (int k = 0; k < nb; ++k) {
         for (int gi : by_band[(size_t)k]) {
             band_rows[(size_t)k] += groups[(size_t)gi].n + groups[(size_t)gi].b;
@@ -900,7 +903,8 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             frb = rows >= 4096 ? 4 : (rows >= 2048 ? 2 : 1);
             fnb = (rows < 1024 && big_ok) ? 1024 : 256;
         }
-        if (cols >= 1536 || !big_ok) { bnb = 256; bcb = cols >= 4096 ? 4 : (cols >= 2048 ? 2 : 1); }
+        // (two-mode lanes split a dot product over twice as many parts per workgroup: 256 threads reach further down)
+        if (cols >= (two_modes ? 1024 : 1536) || !big_ok) { bnb = 256; bcb = cols >= 4096 ? 4 : (cols >= 2048 ? 2 : 1); }
         else { bnb = 1024; bcb = cols >= 400 ? 2 : 1; }
         c->front_fwd_rb[k] = std::min(frb, c->front_rb_max);
         c->front_bwd_cb[k] = std::min(bcb, c->front_rb_max);
