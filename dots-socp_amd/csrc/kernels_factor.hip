@@ -15,6 +15,7 @@
 #include "dots_dev.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace dots {
@@ -140,50 +141,61 @@ __global__ __launch_bounds__(256) void k_fact_panel(FactArgs g, FrontDev f, int 
     }
 }
 
-// ---- trailing update with the panel [k0, k0 + we): 8 x 8 tiles of the m x m front (columns >= n live in S) ---
+// ---- trailing update with the panel [k0, k0 + we): 16 x 16 tiles of the m x m front (columns >= n live in S); the 8 threads
+// of a mode take 4 rows x 8 columns each, so that a panel entry loaded once serves 8 (4) products: 12 loads per 32
+// multiply-adds.  (An 8 x 8 tiling with one row per thread, 9 loads per 8 multiply-adds, took 2.6 x as long: DESIGN.md 8.)
 __global__ __launch_bounds__(256) void k_fact_update(FactArgs g, FrontDev f, int k0, int w, int tiles_per_row) {
     const FrontNode nd = f.nodes[g.level_nodes[blockIdx.y]];
     const int n = nd.n, b = nd.b, m = n + b;
     if (k0 >= n) return;
     const int we = min(w, n - k0);
     const int ti = blockIdx.x / tiles_per_row, tj = blockIdx.x % tiles_per_row;
-    const int i0 = ti * 8, j0 = tj * 8;
+    const int i0 = ti * 16, j0 = tj * 16;
     if (i0 >= m || j0 >= m) return;
     const int jlo = k0 + we;                    // first column that still changes
-    if (j0 + 8 <= jlo) return;
-    if (j0 < n) { if (i0 + 8 <= j0) return; }  // strictly above the diagonal of the L part
-    else if (i0 + 8 <= n) return;               // S columns only take S rows
+    if (j0 + 16 <= jlo) return;
+    if (j0 < n) { if (i0 + 16 <= j0) return; }  // strictly above the diagonal of the L part
+    else if (i0 + 16 <= n) return;              // S columns only take S rows
     const int sh = g.sh, tid = threadIdx.x;
     const int a = tid & (g.TP - 1);
     if (a >= g.ncol) return;
-    const int Q = 256 >> sh;
+    const int Q = 256 >> sh;                    // threads per mode
     const double *__restrict__ Cp = g.C + (nd.foff << sh) + a;
-    for (int q = tid >> sh; q < 8; q += Q) {
-        const int i = i0 + q;
-        if (i >= m) continue;
-        double li[16], acc[8];
-        const double *__restrict__ ri = Cp + (((int64_t)i * n + k0) << sh);
+    // sub-tiles of 4 rows x 8 columns: 8 per tile, dealt to the mode's threads
+    for (int st = tid >> sh; st < 8; st += Q) {
+        const int ib = i0 + (st >> 1) * 4, jb = j0 + (st & 1) * 8;
+        double acc[4][8];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) li[t] = t < we ? ri[(int64_t)t << sh] : 0.0;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int j = j0 + jj;
-            double s = 0.0;
-            const bool need = j < m && j >= jlo && (j < n ? i >= j : i >= n);
-            if (need) {
-                const double *__restrict__ rj = Cp + (((int64_t)j * n + k0) << sh);
+            for (int cc = 0; cc < 8; ++cc) acc[r][cc] = 0.0;
+        const double *ri[4], *rj[8];
 #pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    if (t < we) s += li[t] * rj[(int64_t)t << sh];
-            }
-            acc[jj] = s;
+        for (int r = 0; r < 4; ++r) ri[r] = Cp + (((int64_t)min(ib + r, m - 1) * n + k0) << sh);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) rj[cc] = Cp + (((int64_t)min(jb + cc, m - 1) * n + k0) << sh);
+        for (int t = 0; t < we; ++t) {
+            double li[4], lj[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) li[r] = ri[r][(int64_t)t << sh];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) lj[cc] = rj[cc][(int64_t)t << sh];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) acc[r][cc] += li[r] * lj[cc];
         }
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int j = j0 + jj;
-            if (!(j < m && j >= jlo && (j < n ? i >= j : i >= n))) continue;
-            if (j < n) g.C[((nd.foff + (int64_t)i * n + j) << sh) + a] -= acc[jj];
-            else g.S[((nd.soff + (int64_t)(i - n) * b + (j - n)) << sh) + a] -= acc[jj];
+        for (int r = 0; r < 4; ++r) {
+            const int i = ib + r;
+            if (i >= m) continue;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                const int j = jb + cc;
+                if (!(j < m && j >= jlo && (j < n ? i >= j : i >= n))) continue;
+                if (j < n) g.C[((nd.foff + (int64_t)i * n + j) << sh) + a] -= acc[r][cc];
+                else g.S[((nd.soff + (int64_t)(i - n) * b + (j - n)) << sh) + a] -= acc[r][cc];
+            }
         }
     }
 }
@@ -201,14 +213,15 @@ __global__ __launch_bounds__(256) void k_fact_linv(FactArgs g, FrontDev f) {
     const bool ground = nd.parent < 0 && g.grounded[a];
     for (int i = j; i < n; ++i) {
         const double *__restrict__ Li = L + (((int64_t)i * n) << sh);
-        double s0 = (i == j) ? 1.0 : 0.0, s1 = 0.0;
+        // 8 partial sums: the loop is a chain of L2 round trips, 16 loads in flight per lane instead of 4
+        double s[8] = {(i == j) ? 1.0 : 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int k = j;
-        for (; k + 2 <= i; k += 2) {
-            s0 -= Li[(int64_t)k << sh] * X[((int64_t)k * n + j) << sh];
-            s1 -= Li[(int64_t)(k + 1) << sh] * X[((int64_t)(k + 1) * n + j) << sh];
+        for (; k + 8 <= i; k += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] -= Li[(int64_t)(k + u) << sh] * X[((int64_t)(k + u) * n + j) << sh];
         }
-        for (; k < i; ++k) s0 -= Li[(int64_t)k << sh] * X[((int64_t)k * n + j) << sh];
-        double x = (s0 + s1) / Li[(int64_t)i << sh];
+        for (; k < i; ++k) s[0] -= Li[(int64_t)k << sh] * X[((int64_t)k * n + j) << sh];
+        double x = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) / Li[(int64_t)i << sh];
         if (ground && i == n - 1) x = 0.0;
         X[((int64_t)i * n + j) << sh] = x;
     }
@@ -227,14 +240,14 @@ __global__ __launch_bounds__(256) void k_fact_gmat(FactArgs g, FrontDev f) {
     for (int64_t e = (int64_t)blockIdx.x * Q + q; e < total; e += (int64_t)gridDim.x * Q) {
         const int r = (int)(e / n), j = (int)(e % n);
         const double *__restrict__ Lr = L + (((int64_t)(n + r) * n) << sh);
-        double s0 = 0.0, s1 = 0.0;
+        double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int k = j;
-        for (; k + 2 <= n; k += 2) {
-            s0 += Lr[(int64_t)k << sh] * X[((int64_t)k * n + j) << sh];
-            s1 += Lr[(int64_t)(k + 1) << sh] * X[((int64_t)(k + 1) * n + j) << sh];
+        for (; k + 8 <= n; k += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += Lr[(int64_t)(k + u) << sh] * X[((int64_t)(k + u) * n + j) << sh];
         }
-        for (; k < n; ++k) s0 += Lr[(int64_t)k << sh] * X[((int64_t)k * n + j) << sh];
-        X[((int64_t)(n + r) * n + j) << sh] = s0 + s1;
+        for (; k < n; ++k) s[0] += Lr[(int64_t)k << sh] * X[((int64_t)k * n + j) << sh];
+        X[((int64_t)(n + r) * n + j) << sh] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
 }
 
@@ -293,7 +306,7 @@ int front_factorize(Ctx *c, const dots_front_desc *h, FrontDev &f, const std::ve
         auto blocks = [&](int64_t items) { return (unsigned)std::min<int64_t>(std::max<int64_t>((items + Q - 1) / Q, 1), 4096); };
         hipLaunchKernelGGL(k_fact_assemble, dim3(blocks(max_e), cnt), dim3(256), 0, c->stream, g, f);
         const int rows_per_wg = 8 * Q;
-        const int tiles = (max_m + 7) / 8;
+        const int tiles = (max_m + 15) / 16;
         for (int k0 = 0; k0 < max_n; k0 += w) {
             const int below = std::max(max_m - (k0 + 1), 0);
             const size_t lds = sizeof(double) * (size_t)w * w * d.TP;
