@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- ALM iterations per second of the DOTs-SOCP hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload knot|sphere10k|knot63|torus100k|torus65k_T127|plane20]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload knot|sphere10k|knot63|torus100k|torus65k_T127|torus500k|plane20]
 
 One "step" is one full pass of the solver's main loop (reference solver_socp.py:656-823): steps 1-3 (Laplacian solve,
 cone projection, (q, lambda) + multiplier update) plus whatever KKT evaluation / penalty update the reference's lazy
@@ -47,11 +47,13 @@ WORKLOADS = {
     "torus100k": dict(example="torus", kw=dict(nu=400, nv=250), n_time=31, congestion=0.0, tol=1e-3, config=3),
     # configs[4] stand-in: 360 x 180 torus, V = 64 800, ntime=127 (time pitch 128), tol 1e-5
     "torus65k_T127": dict(example="torus", kw=dict(nu=360, nv=180), n_time=127, congestion=0.0, tol=1e-5, config=4),
+    # scale check beyond the configurations (not a bench line): 1000 x 500 torus, V = 500 000, factor ~10 GB
+    "torus500k": dict(example="torus", kw=dict(nu=1000, nv=500), n_time=31, congestion=0.0, tol=1e-3, config=None),
     # the survey's analytic case
     "plane20": dict(example="plane", kw=dict(n=20), n_time=31, congestion=0.0, tol=1e-3, config=None),
 }
 ALL_CONFIGS = ["knot", "sphere10k", "knot63", "torus100k", "torus65k_T127"]
-STEADY = {"torus65k_T127": (40, 100), "torus100k": (100, 200)}     # (first timed iteration, timed iterations); default (100, 200)
+STEADY = {"torus65k_T127": (40, 100), "torus100k": (100, 200), "torus500k": (20, 40)}     # (first timed iteration, timed iterations); default (100, 200)
 
 
 def parse():
