@@ -315,3 +315,58 @@ def test_time_limit_stops_every_rank_on_the_same_iteration():
     results = run_ranks(3, lambda comm: solver_socp_sharded(15, geom, comm=comm, nit=100000, tol=1e-30, time_limit=0.3))
     its = [int(h.kkt_iteration[-1]) for _, h in results]
     assert len(set(its)) == 1 and 5 < its[0] < 100000
+
+
+def _rccl_worker(rank, world, port, fname, out_dir):
+    """One rank of a torch.distributed job over RCCL (backend "nccl") driving the real device path."""
+    import sys
+
+    from conftest import ROOT
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from dots_socp_amd.distributed import TorchComm, solver_socp_sharded
+
+        g = golden(fname)
+        kw = {k[3:]: (g[k].tolist() if g[k].ndim else g[k].item()) for k in g.files if k.startswith("kw_")}
+        comm = TorchComm()
+        assert comm.backend == "nccl" and comm.size == world
+        sol, hist = solver_socp_sharded(int(g["n_time"]), geom_of(g), comm=comm, device=0, lap_solver="modal_direct", **kw)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), kkt=hist.kkt_errors, it=hist.kkt_iteration,
+                 cost=hist.history["Transportation cost"], mu=sol["mu"], calls=np.array([comm.calls[k] for k in sorted(comm.calls)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fname", ["run_ico2_T15_cong_tol1e-3.npz", "run_torus_T7_tol1e-4.npz"])
+def test_rccl_backend_single_rank(fname, tmp_path):
+    """The sharded driver over RCCL itself (device tensors handed to all_gather_into_tensor / all_reduce, ordering against the
+    library's stream): one GPU allows one rank, so the neighbour exchanges stay with the thread and gloo tests; the collectives,
+    the buffers they are given and the stream hand-overs are the ones an N-GPU job runs."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_worker, args=(1, port, fname, str(tmp_path)), nprocs=1, join=True)
+    g = golden(fname)
+    r = np.load(tmp_path / "rank0.npz")
+    want = g["hist_kkt_errors"]
+    assert int(r["it"][-1]) == int(g["last_iteration"])
+    assert np.array_equal(np.isnan(r["kkt"]), np.isnan(want))
+    m = ~np.isnan(want)
+    assert np.allclose(r["kkt"][m], want[m], rtol=1e-6, atol=1e-13)
+    assert np.allclose(r["cost"], g["hist_Transportation_cost"], rtol=1e-6, equal_nan=True)
+    assert np.max(np.abs(r["mu"] - g["sol_mu"])) < 1e-5 * np.max(np.abs(g["sol_mu"]))
+    calls = dict(zip(sorted(["all_gather", "exchange", "all_reduce", "flag"]), r["calls"].tolist()))
+    assert calls["all_gather"] > 0 and calls["all_reduce"] > 0
