@@ -899,13 +899,14 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         } else if (band_planes[(size_t)k] >= 4) {
             if (rows >= 600 || !big_ok) { fnb = 256; frb = 4; }
             else { fnb = 1024; frb = rows >= 300 ? 2 : 1; }
-        } else {
-            frb = rows >= 4096 ? 4 : (rows >= 2048 ? 2 : 1);
+        } else {      // (thresholds from the tables of profiles/studies/shape_tuner.txt)
             fnb = (rows < 1024 && big_ok) ? 1024 : 256;
+            frb = fnb == 1024 ? (rows >= 512 ? 2 : 1) : (rows >= 2048 ? 4 : 2);
         }
-        // (two-mode lanes split a dot product over twice as many parts per workgroup: 256 threads reach further down)
-        if (cols >= (two_modes ? 1024 : 1536) || !big_ok) { bnb = 256; bcb = cols >= 4096 ? 4 : (cols >= 2048 ? 2 : 1); }
-        else { bnb = 1024; bcb = cols >= 400 ? 2 : 1; }
+        // (two-mode lanes split a dot product over twice as many parts per workgroup: 256 threads reach further down; at a pitch of
+        // 128 a 256-thread workgroup splits a dot product only 4 ways: 1024 threads up to 3000 columns)
+        if (cols >= (d.TP >= 128 ? 3000 : (two_modes ? 1024 : 1536)) || !big_ok) { bnb = 256; bcb = cols >= 4096 ? 4 : (cols >= 2048 ? 2 : 1); }
+        else { bnb = 1024; bcb = (d.TP >= 128 && cols >= 600) ? 4 : (cols >= 250 ? 2 : 1); }
         c->front_fwd_rb[k] = std::min(frb, c->front_rb_max);
         c->front_bwd_cb[k] = std::min(bcb, c->front_rb_max);
         c->front_fwd_nb[k] = fnb;
