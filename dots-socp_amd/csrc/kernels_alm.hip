@@ -403,7 +403,7 @@ __global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double 
 }
 
 // T + 1 >= 64: 32 vertices per workgroup, the transform on the matrix cores.
-__global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, double eps, double *__restrict__ bhat, int n_rhs, double sz, double cd) {
+__global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, double eps, double *__restrict__ bhat, int n_rhs, int n_tiles, double sz, double cd) {
     if ((int)blockIdx.x >= n_rhs) {      // riders: the cone projection of a tile, as in k_rhs_modes
         const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
         if (st >= d.n_vtiles) return;
@@ -413,7 +413,9 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, doub
     }
     extern __shared__ double xs_m[];                    // [TM_ROWS][TP + 1]
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1;
-    const int v0 = blockIdx.x * TM_ROWS;
+    const int tile = xcd_tile(blockIdx.x, n_tiles);     // neighbouring tiles walk the same triangles: one XCD (one L2) for a run of them
+    if (tile >= n_tiles) return;
+    const int v0 = tile * TM_ROWS;
     for (int e = threadIdx.x; e < TM_ROWS * TP; e += RHS_NB) {
         const int vl = e >> d.tp_shift, t = e & (TP - 1);
         xs_m[vl * TPp + t] = (v0 + vl < d.V && t < n) ? rhs_value(d, v0 + vl, t, r, eps) : 0.0;
@@ -425,9 +427,9 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, doub
 int launch_rhs(Ctx *c, bool with_soc) {
     const int g = xcd_grid(c->d.n_vtiles);
     if (rhs_writes_modes(c) && time_modes_mfma_ok(c->d)) {      // (two time columns per lane measured here too: knot63 -1.5 %, torus65k_T127 +1.5 %: not kept)
-        const int n_rhs = (c->d.V + TM_ROWS - 1) / TM_ROWS;
+        const int n_tiles = (c->d.V + TM_ROWS - 1) / TM_ROWS, n_rhs = xcd_grid(n_tiles);
         hipLaunchKernelGGL(k_rhs_modes_mfma, dim3(n_rhs + (with_soc ? g : 0)), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
-                           c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, c->prm.scale_z, c->prm.const_d);
+                           c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, n_tiles, c->prm.scale_z, c->prm.const_d);
     }
     else if (rhs_writes_modes(c) && c->rhs_two && c->d.TP >= 4)      // two time columns per lane (16-byte accesses)
         hipLaunchKernelGGL(k_rhs_modes2, dim3(with_soc ? 2 * g : g), dim3(RHS_NB2), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
