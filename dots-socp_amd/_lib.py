@@ -10,7 +10,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libdotsocp_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ARRAY_IDS = {
     "phi": 0, "A": 1, "B": 2, "lambda_c": 3, "z_fst": 4, "z_mid": 5, "z_end": 6,
@@ -18,7 +18,7 @@ ARRAY_IDS = {
 }
 LAP_SOLVERS = {"spacetime_pcg": 0, "modal_pcg": 1}
 PHASES = {"laplacian": 0, "soc_projection": 1, "q_lambda_mult": 2, "q_lambda": 3}
-STEP_SKIP_Z_MID, STEP_PALM = 1, 2
+STEP_SKIP_Z_MID, STEP_PALM, STEP_RHS_AHEAD = 1, 2, 4
 OPERATORS = {
     "grad_time": 0, "div_time": 1, "grad_space": 2, "div_space": 3, "decouple": 4,
     "decouple_adjoint": 5, "time_avg_adjoint": 6, "laplacian_apply": 7,

@@ -257,10 +257,13 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     return 0;
 }
 
-static int check(dots_ctx *ctx) {
+// `reads_only`: the entry point changes neither the state nor the parameters.  Every other one drops a right-hand side that was
+// enqueued ahead of its iteration (DOTS_STEP_RHS_AHEAD): the next dots_step then computes it again.
+static int check(dots_ctx *ctx, bool reads_only = false) {
     if (!ctx) { set_error("null context"); return DOTS_ERR_ARGUMENT; }
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
+    if (!reads_only) ctx->rhs_ahead = ctx->rhs_ahead_armed = 0;
     return 0;
 }
 
@@ -313,21 +316,25 @@ static int slab_stage(Ctx *c, int stage) {
 static int run_iteration(Ctx *c, dots_step_stats *st) {
     int rc;
     if ((rc = palm_step0(c))) return rc;
+    // the right-hand side of this iteration was enqueued behind the KKT kernels of the last one (DOTS_STEP_RHS_AHEAD) and nothing
+    // it reads has changed since: start at the solve; the projection then runs with the inverse transform
+    const bool ahead = c->rhs_ahead && !c->step_palm;
+    c->rhs_ahead = 0;
     if (!st) {   // asynchronous: enqueue only (the direct solver needs no host round trip); nothing is timed
         c->zmid_stale = c->step_skip_zmid;
-        if (rhs_takes_soc(c)) {   // [right-hand side + projection] -> sweeps -> inverse transform -> steps 2+3
+        if (rhs_takes_soc(c) && !ahead) {   // [right-hand side + projection] -> sweeps -> inverse transform -> steps 2+3
             if ((rc = launch_rhs(c, true))) return rc;
             if ((rc = cg_solve(c, nullptr))) return rc;
             return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
         }
         const bool fuse = soc_takes_inverse(c);
-        if ((rc = launch_rhs(c))) return rc;
+        if (!ahead && (rc = launch_rhs(c))) return rc;
         if ((rc = cg_solve(c, nullptr, fuse))) return rc;
         if ((rc = launch_soc_projection(c, 1, fuse))) return rc;
         return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
     }
     DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
-    if ((rc = launch_rhs(c))) return rc;
+    if (!ahead && (rc = launch_rhs(c))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
     const bool fuse = soc_takes_inverse(c);
     if ((rc = cg_solve(c, st, fuse))) return rc;
@@ -415,6 +422,9 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);
     int rc = build(c, desc);
     if (rc) { dots_destroy(c); return rc; }
+    preload_alm_kernels();
+    preload_kkt_kernels();
+    preload_transform_kernels();
     *out = c;
     return 0;
 }
@@ -449,7 +459,7 @@ int dots_get_params(dots_ctx *c, dots_params *p) {
     return 0;
 }
 int dots_sync(dots_ctx *c) {
-    int rc = check(c);
+    int rc = check(c, true);
     if (rc) return rc;
     DOTS_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -473,7 +483,7 @@ int dots_upload(dots_ctx *c, int id, const double *host, int64_t count) {
     return 0;
 }
 int dots_download(dots_ctx *c, int id, double *host, int64_t count) {
-    int rc = check(c);
+    int rc = check(c, true);
     if (rc) return rc;
     if (id < 0 || id >= DOTS_N_ARRAYS || !host || count != array_count_host(c->d, id)) { set_error("download: bad array id or element count"); return DOTS_ERR_ARGUMENT; }
     if (id == DOTS_Z_MID && c->zmid_stale) { set_error("download: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
@@ -573,7 +583,7 @@ int dots_stream_wait(dots_ctx *c, void *other_stream, int ctx_waits) {
 }
 
 int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
-    int rc = check(c);
+    int rc = check(c, true);      // (run_iteration consumes the flag itself)
     if (rc) return rc;
     if (n_iters < 0) { set_error("n_iters < 0"); return DOTS_ERR_ARGUMENT; }
     if (c->shard_stride != 0) { set_error("dots_step on a time slab: use dots_slab_stage"); return DOTS_ERR_STATE; }
@@ -586,9 +596,11 @@ int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
 }
 
 int dots_step_flags(dots_ctx *c, uint32_t flags) {
-    int rc = check(c);
+    int rc = check(c, true);
     if (rc) return rc;
-    if (flags & ~(uint32_t)(DOTS_STEP_SKIP_Z_MID | DOTS_STEP_PALM)) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
+    if (flags & ~(uint32_t)(DOTS_STEP_SKIP_Z_MID | DOTS_STEP_PALM | DOTS_STEP_RHS_AHEAD)) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
+    if ((flags & DOTS_STEP_RHS_AHEAD) && (flags & DOTS_STEP_PALM)) { set_error("step_flags: DOTS_STEP_RHS_AHEAD cannot be combined with DOTS_STEP_PALM (its step 0 changes what the right-hand side reads)"); return DOTS_ERR_ARGUMENT; }
+    c->rhs_ahead_armed = ((flags & DOTS_STEP_RHS_AHEAD) && rhs_writes_modes(c)) ? 1 : 0;      // (a hint: ignored without the direct solver / on a time slab)
     if ((flags & DOTS_STEP_SKIP_Z_MID) && (flags & DOTS_STEP_PALM)) { set_error("step_flags: DOTS_STEP_PALM reads z_mid, it cannot be combined with DOTS_STEP_SKIP_Z_MID"); return DOTS_ERR_ARGUMENT; }
     c->step_skip_zmid = (flags & DOTS_STEP_SKIP_Z_MID) ? 1 : 0;
     c->step_palm = (flags & DOTS_STEP_PALM) ? 1 : 0;
@@ -621,7 +633,7 @@ int dots_run_phase(dots_ctx *c, int phase, dots_step_stats *stats) {
 }
 
 int dots_kkt(dots_ctx *c, uint32_t mask, double *out) {
-    int rc = check(c);
+    int rc = check(c, true);
     if (rc) return rc;
     if (!out || (mask >> DOTS_N_KKT)) { set_error("kkt: bad mask or null output"); return DOTS_ERR_ARGUMENT; }
     if (!mask) return 0;
@@ -630,7 +642,7 @@ int dots_kkt(dots_ctx *c, uint32_t mask, double *out) {
     return kkt_evaluate(c, mask, out);
 }
 int dots_kkt_sums(dots_ctx *c, uint32_t mask, double *sums) {
-    int rc = check(c);
+    int rc = check(c, true);
     if (rc) return rc;
     if (!sums || (mask >> DOTS_N_KKT)) { set_error("kkt_sums: bad mask or null output"); return DOTS_ERR_ARGUMENT; }
     static_assert(DOTS_KKT_N_SUMS == MAX_SUMS, "header and kernels disagree on the number of KKT sums");
@@ -644,26 +656,26 @@ int dots_kkt_sums(dots_ctx *c, uint32_t mask, double *sums) {
     return kkt_sums(c, mask, sums);
 }
 int dots_kkt_combine(dots_ctx *c, uint32_t mask, const double *sums, double *out) {
-    int rc = check(c);
+    int rc = check(c, true);
     if (rc) return rc;
     if (!sums || !out || (mask >> DOTS_N_KKT)) { set_error("kkt_combine: bad argument"); return DOTS_ERR_ARGUMENT; }
     return kkt_combine(c, mask, sums, out);
 }
 int dots_objective_sums(dots_ctx *c, double *sums) {
-    int rc = check(c);
+    int rc = check(c, true);
     if (rc) return rc;
     if (!sums) { set_error("null output"); return DOTS_ERR_ARGUMENT; }
     return objective_sums(c, sums);
 }
 int dots_objective_combine(dots_ctx *c, const double *sums, double *out) {
-    int rc = check(c);
+    int rc = check(c, true);
     if (rc) return rc;
     if (!sums || !out) { set_error("null argument"); return DOTS_ERR_ARGUMENT; }
     return objective_combine(c, sums, out);
 }
 
 int dots_objective(dots_ctx *c, double *out) {
-    int rc = check(c);
+    int rc = check(c, true);
     if (rc) return rc;
     if (!out) { set_error("null output"); return DOTS_ERR_ARGUMENT; }
     if (c->shard_stride != 0) { set_error("objective on a time slab: use dots_objective_sums / dots_objective_combine"); return DOTS_ERR_STATE; }

@@ -192,6 +192,9 @@ struct Ctx;
 
 // ---- launch wrappers implemented in the kernel files (all asynchronous on ctx stream) ----
 int launch_soc_projection(Ctx *c, int zmid_mode = 0, bool with_inverse = false);   // 0: write z_mid; 1: write only the cone multiplier; with_inverse: extra workgroups do the modes -> time transform of phi
+void preload_alm_kernels();
+void preload_kkt_kernels();
+void preload_transform_kernels();
 int launch_rhs(Ctx *c, bool with_soc = false);   // with_soc (only when rhs_takes_soc): the cone projection rides in the same launch
 int launch_q_lambda_mult(Ctx *c, int zmid_mode = 0);    // 0: read z_mid; 1: rebuild it from the multiplier and store it; 2: rebuild, do not store
 int launch_q_lambda_only(Ctx *c);                       // the (q, lambda_c) closed form alone (is_palm's step 0): z_mid is read from memory
@@ -275,6 +278,8 @@ struct Ctx {
     int front_fwd_nb[65]{}, front_bwd_nb[65]{};     // threads per workgroup on each level (256, or 1024 where a level has few rows)
     int front_planes[65]{};       // update planes the forward launch of a band reads per node (0, 2, 4 or 8)
     int front_vec2 = 1;           // two modes per lane in the sweeps (DOTS_FRONT_VEC2: 0 never, 1 / 2 wherever the pitch allows, 3 only where bandwidth-bound)
+    int rhs_ahead_armed = 0;      // DOTS_STEP_RHS_AHEAD: the next KKT launch is followed by the next iteration's right-hand side
+    int rhs_ahead = 0;            // ... which is on the stream and still valid (any call that changes state or parameters clears it)
     int front_rb_max = 4;         // most rows (columns) of a node per workgroup (DOTS_FRONT_RB: 1, 2 or 4, for A/B measurements)
     double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps, merged blocks as stored)
     double front_bytes_unmerged = 0.0;   // the same for one launch per tree height (no merged bands)

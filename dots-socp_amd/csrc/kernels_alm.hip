@@ -971,4 +971,20 @@ int launch_operator(Ctx *c, int op, double scale, const double *in, double *out)
     return 0;
 }
 
+// The runtime prepares a kernel on its first use (several hundred microseconds each): do that for the kernels of an iteration when
+// the context is created, not inside the first iterations that happen to use them.
+void preload_alm_kernels() {
+    const void *fns[] = {
+        (const void *)k_rhs, (const void *)k_rhs_modes, (const void *)k_rhs_modes2, (const void *)k_rhs_modes_mfma,
+        (const void *)k_soc_projection<true>, (const void *)k_soc_projection<false>,
+        (const void *)k_q_lambda_mult_triangle<0>, (const void *)k_q_lambda_mult_triangle<1>, (const void *)k_q_lambda_mult_triangle<2>,
+        (const void *)k_q_lambda_mult_triangle<0, true>,
+        (const void *)k_q_lambda_mult_triangle2<0>, (const void *)k_q_lambda_mult_triangle2<1>, (const void *)k_q_lambda_mult_triangle2<2>,
+        (const void *)k_divide_five, (const void *)k_scale, (const void *)k_divide, (const void *)k_rebuild_mu, (const void *)k_rebuild_E,
+    };
+    hipFuncAttributes a;
+    for (const void *f : fns) (void)hipFuncGetAttributes(&a, f);
+    (void)hipGetLastError();
+}
+
 }  // namespace dots

@@ -907,4 +907,13 @@ int cg_bench(Ctx *c, int which, int reps, double *ms, double *bytes) {
     return 0;
 }
 
+void preload_transform_kernels() {      // (see preload_alm_kernels)
+    const void *fns[] = {(const void *)k_time_modes_tile<true, BLOCK>, (const void *)k_time_modes_tile<false, BLOCK>,
+                         (const void *)k_time_modes_tile<false, 1024>, (const void *)k_time_modes_mfma,
+                         (const void *)k_time_modes<true>, (const void *)k_time_modes<false>};
+    hipFuncAttributes a;
+    for (const void *f : fns) (void)hipFuncGetAttributes(&a, f);
+    (void)hipGetLastError();
+}
+
 }  // namespace dots

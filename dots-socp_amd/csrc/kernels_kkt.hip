@@ -303,6 +303,13 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
         const double seq = (double)(++c->mail_seq);
         hipLaunchKernelGGL(k_reduce_mail, dim3(N_SUMS), dim3(BLOCK), 0, c->stream, d.partials, nv, part_f, nf, c->d.scal + S::SUMS, c->h_mail, seq, c->kkt_counter);
         DOTS_HIP(hipGetLastError());
+        // DOTS_STEP_RHS_AHEAD: while the host waits for these sums and decides, the device starts on the next iteration's
+        // right-hand side (it reads only what the next dots_step would read; dots_api.hip: check() drops it if anything changes)
+        if (c->rhs_ahead_armed) {
+            c->rhs_ahead_armed = 0;
+            if ((rc = launch_rhs(c))) return rc;
+            c->rhs_ahead = 1;
+        }
         rc = wait_mail(c, seq, N_SUMS);
     } else {
         if (nv && (rc = reduce_partials(c, d.partials, N_VSUMS, nv, 0))) return rc;
@@ -497,6 +504,14 @@ int norm_square(Ctx *c, int id, int part, double *out) {
     if (part == 2) avg = d.T + 1;
     *out = c->h_pinned[0] / avg;
     return 0;
+}
+
+void preload_kkt_kernels() {      // (see preload_alm_kernels)
+    const void *fns[] = {(const void *)k_kkt_sums, (const void *)k_reduce_slots, (const void *)k_mail_sums, (const void *)k_reduce_mail,
+                         (const void *)k_objective, (const void *)k_norm};
+    hipFuncAttributes a;
+    for (const void *f : fns) (void)hipFuncGetAttributes(&a, f);
+    (void)hipGetLastError();
 }
 
 }  // namespace dots

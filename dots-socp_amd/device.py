@@ -163,8 +163,10 @@ class DeviceProblem:
         _lib.check(self.lib.dots_step(self._h, int(n_iters), C.byref(st)), "dots_step")
         return st
 
-    def step_flags(self, skip_z_mid=False, palm=False):
-        flags = (_lib.STEP_SKIP_Z_MID if skip_z_mid else 0) | (_lib.STEP_PALM if palm else 0)
+    def step_flags(self, skip_z_mid=False, palm=False, rhs_ahead=False):
+        """``rhs_ahead`` (DOTS_STEP_RHS_AHEAD): the first KKT read-back after the next step also enqueues the right-hand side of
+        the iteration after it; only meaningful with the direct solver on one GPU."""
+        flags = (_lib.STEP_SKIP_Z_MID if skip_z_mid else 0) | (_lib.STEP_PALM if palm else 0) | (_lib.STEP_RHS_AHEAD if rhs_ahead else 0)
         _lib.check(self.lib.dots_step_flags(self._h, flags), "dots_step_flags")
 
     # ---- time slab (multi-GPU): stages of one iteration around the caller's exchanges (dots_slab_stage)

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import logging
 import math
+import os
 import time
 
 import numpy as np
@@ -76,6 +77,16 @@ class AlmSolver:
         self.untimed_steps = 0          # iterations whose phases were not timed (run_history.steps_time holds the others)
         self.quiet_steps = 0            # iterations after which nothing was read back
         self._read_back_steps = 0
+        # the right-hand side of the iteration after a read-back may be enqueued ahead (iterate(); DOTS_RHS_AHEAD=0 never, =2 always).
+        # Only on small problems: the iteration that follows runs its projection apart from its right-hand side, which costs more
+        # than the idle time it fills once the kernels are bandwidth-bound, and one launch more from T + 1 = 64 on (measured on the
+        # driver's 20 steps: plane20 +2.5 %, knot +1.5 %, sphere10k +0.3 %, knot63 -0.7 %, torus100k -2.5 %)
+        ahead = os.environ.get("DOTS_RHS_AHEAD", "1")
+        self._rhs_ahead_ok = (direct and time_slab is None and not self.is_palm and not check_kkt_step_by_step
+                              and not is_constant_scaling and ahead != "0"
+                              and (ahead == "2" or (int(n_time) + 1 < 64
+                                                    and np.asarray(geometry["vertices"]).shape[0] * (int(n_time) + 1) <= 200_000)))
+        self._rhs_ahead = False
         if direct and reorder is True:
             reorder = "nd"      # the elimination order of the factor doubles as the locality numbering
         self.dev = dev = DeviceProblem(n_time, geometry, lap_solver="modal_pcg" if direct else lap_solver, device=device,
@@ -262,7 +273,7 @@ class AlmSolver:
         ``quiet``: nothing is read back after this iteration (no KKT evaluation, not the last one): z_mid
         need not be stored, and with the direct solver the host does not wait for the device either."""
         # is_palm's step 0 reads z_mid of the previous iteration: it is stored every iteration then
-        self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm)
+        self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, rhs_ahead=self._rhs_ahead and not quiet)
         # With the direct solver an iteration needs no host round trip: it is only enqueued, and on iterations that read
         # back the KKT kernels follow it on the stream (one wait, at the read-back).  The phase timers of the history
         # (Step 1-1 ...: five events and a host wait per iteration) are SAMPLED: the first read-back iterations and every
@@ -313,6 +324,12 @@ class AlmSolver:
         is_time_used_up = self._time_is_up(reads_back)
         quiet = not (is_time_used_up or reads_back)
         self._kkt_cache = {}
+        # An iteration that reads residuals back but changes nothing afterwards (no penalty update: that is known from the
+        # schedule) is followed by an iteration that starts from the state it leaves, unless the run stops or z is rescaled:
+        # the device starts on that iteration's right-hand side while the host waits for the residuals (DOTS_STEP_RHS_AHEAD;
+        # dropped by the library if anything changes in between).
+        self._rhs_ahead = (self._rhs_ahead_ok and reads_back and not is_time_used_up and it + 1 < self.nit
+                           and not params.peek_adjust(it))
         self._device_step(quiet)                                                # steps 1-3 (:674-722)
 
         adjust = params.is_to_adjust(it) or is_time_used_up

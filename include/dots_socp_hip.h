@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DOTS_ABI_VERSION 4
+#define DOTS_ABI_VERSION 5
 
 typedef struct dots_ctx dots_ctx;
 
@@ -173,6 +173,14 @@ int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
  * solver_socp.py:668-672: A, B, lambda_c from the current multipliers, the stored z_mid and grad(phi) of the previous
  * iteration).  It reads z_mid from memory, so it cannot be combined with DOTS_STEP_SKIP_Z_MID (DOTS_ERR_ARGUMENT). */
 #define DOTS_STEP_PALM 2u
+/* DOTS_STEP_RHS_AHEAD (a hint: ignored without the direct solver or on a time slab; DOTS_ERR_ARGUMENT with DOTS_STEP_PALM): the caller expects the
+ * iteration AFTER the next dots_step to start from the state that step leaves (no penalty update, no rescaling in between).
+ * The first dots_kkt / dots_kkt_sums call after that step then enqueues the next iteration's right-hand side behind its own
+ * kernels, so that the device works while the host waits for the residuals and decides; the following dots_step starts at the
+ * solve.  Any call in between that changes the state or the parameters (dots_set_params, dots_upload, dots_adjust_penalty,
+ * dots_scale_*, dots_run_phase, ...) drops that right-hand side and the step computes it again: results never depend on the
+ * flag.  The flag holds for one dots_step. */
+#define DOTS_STEP_RHS_AHEAD 4u
 int dots_step_flags(dots_ctx *ctx, uint32_t flags);      /* also apply to dots_slab_stage */
 
 /* ---- time slabs (multi-GPU): one ALM iteration in four stages around three exchanges --------------------------------

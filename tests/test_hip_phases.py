@@ -268,3 +268,59 @@ def test_lazy_z_mid_steps_are_bit_identical():
     for k in out[0][0]:
         assert np.array_equal(out[0][0][k], out[1][0][k]), k
     assert out[0][1] == out[1][1]
+
+
+def test_right_hand_side_ahead_is_bit_identical_and_dropped_on_changes():
+    """DOTS_STEP_RHS_AHEAD: the KKT read-back after a step enqueues the next iteration's right-hand side; the next step starts at
+    the solve.  Same iterates bit for bit as without it; a penalty update, a rescaling or an upload in between drops the
+    right-hand side (the step computes it again from the changed state)."""
+    from dots_socp_amd._lib import HipLibraryError
+    from dots_socp_amd.device import DeviceProblem
+
+    g = golden("ops_ico1.npz")
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    T = int(g["n_time"])
+
+    def run(ahead):
+        dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+        dev.setup_frontal(leaf=4)
+        dev.set_params(congestion=0.05)
+        res = []
+        for k in range(12):
+            reads = k % 3 != 1
+            dev.step_flags(skip_z_mid=not reads, rhs_ahead=ahead and reads)
+            dev.step(1, wait=False)
+            if reads:
+                res.append(dev.kkt([0, 2, 3]))          # with the flag: followed on the stream by the next right-hand side
+                res.append(dev.kkt([4]))                # a second read-back of the same iteration launches nothing more
+            if k == 3:
+                dev.adjust_penalty(1.7)                 # changes r and five arrays: the right-hand side ahead is dropped
+                dev.set_params(r=1.7)
+            if k == 6:
+                dev.scale_z(2.0, 0.5, 2.0)
+                dev.set_params(scale_z=2.0, const_d=2.0)
+            if k == 8:
+                dev.upload("mu", dev.download("mu") * 1.01)
+        dev.step_flags(skip_z_mid=False)
+        dev.step(1)
+        out = (dev.download_all(), dev.kkt(range(7)), res)
+        dev.close()
+        return out
+
+    a, b = run(False), run(True)
+    for k in a[0]:
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert a[1] == b[1] and a[2] == b[2]
+    # the flag cannot be combined with is_palm's step 0
+    dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+    dev.setup_frontal(leaf=4)
+    with pytest.raises(HipLibraryError):
+        dev.step_flags(palm=True, rhs_ahead=True)
+    dev.close()
+    # ... and is a no-op without the direct solver
+    dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+    dev.set_params(cg_tol=1e-10)
+    dev.step_flags(rhs_ahead=True)
+    dev.step(1)
+    assert np.isfinite(dev.kkt([0])[0][0])
+    dev.close()

@@ -197,3 +197,20 @@ def test_smallest_problems_match_the_oracle(case):
     assert np.allclose(hist.history["Transportation cost"], ref_hist.history["Transportation cost"], rtol=1e-6, atol=1e-14)
     for k in ("mu", "E", "A", "B"):
         assert rel(sol[k], ref_sol[k]) < 1e-6, k
+
+
+@pytest.mark.parametrize("fname", ["run_ico2_T15_cong_tol1e-3.npz", "run_torus_T7_tol1e-4.npz"])
+def test_right_hand_side_ahead_changes_nothing(fname, monkeypatch):
+    """The solver starts the next iteration's right-hand side behind the KKT kernels of a read-back iteration that changes nothing
+    (DOTS_STEP_RHS_AHEAD; solver_socp.py: iterate): whole runs with it forced on and off are the same bit for bit — iterates,
+    recorded KKT values, stopping iteration — whatever happens in between (penalty updates, z rescalings, the stop)."""
+    g = golden(fname)
+    out = []
+    for mode in ("0", "2"):
+        monkeypatch.setenv("DOTS_RHS_AHEAD", mode)
+        out.append(run_hip(g, lap_solver="modal_direct"))
+    (sol0, hist0), (sol1, hist1) = out
+    assert int(hist0.kkt_iteration[-1]) == int(hist1.kkt_iteration[-1]) == int(g["last_iteration"])
+    assert np.array_equal(hist0.kkt_errors, hist1.kkt_errors, equal_nan=True)
+    for k in ("mu", "E", "A", "B", "phi", "z_fst", "z_mid", "z_end", "beta_fst", "beta_mid", "beta_end", "lambda_c"):
+        assert np.array_equal(sol0[k], sol1[k]), k
