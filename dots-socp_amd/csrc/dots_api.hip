@@ -413,6 +413,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
     if (const char *e = getenv("DOTS_MG_TAIL_ROWS")) c->mg_tail_rows = atoi(e);
     if (const char *e = getenv("DOTS_SOC_WITH_RHS")) c->soc_with_rhs = atoi(e) != 0;
     if (const char *e = getenv("DOTS_QL_TWO")) c->ql_two = atoi(e);
+    if (const char *e = getenv("DOTS_KKT_TWO")) c->kkt_two = atoi(e);
     if (const char *e = getenv("DOTS_RHS_TWO")) c->rhs_two = atoi(e);
     if (const char *e = getenv("DOTS_SPIN_FETCH")) c->spin_fetch = atoi(e);
     if (const char *e = getenv("DOTS_FRONT_VEC2")) c->front_vec2 = atoi(e);      // 0 never, 1 / 2 wherever the pitch allows (default), 3 only where bandwidth-bound

@@ -266,6 +266,7 @@ struct Ctx {
     int mg_tail_rows = 256;       // levels with at most this many rows run inside the single tail launch (DOTS_MG_TAIL_ROWS)
     int cg_graph_mg = -1;
     int soc_with_rhs = 1;         // DOTS_SOC_WITH_RHS=0: keep the projection after the solve (A/B measurements)
+    int kkt_two = 1;              // KKT sums with two nodes per lane (one GPU; DOTS_KKT_TWO=0: one)
     int ql_two = 1;               // steps 2+3 with two nodes per lane (DOTS_QL_TWO=0: one, for A/B measurements)
     int rhs_two = 1;              // right-hand side + projection with two time columns per lane (DOTS_RHS_TWO=0: one)
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
@@ -353,6 +354,10 @@ __device__ __forceinline__ int64_t idxF(const Dev &d, int f, int c, int t) { ret
 __device__ __forceinline__ int64_t idxM(const Dev &d, int fk, int s, int c, int t) {
     return ((int64_t)((fk * 2 + s) * 3 + c) << d.tp_shift) + t + s;
 }
+// two consecutive time columns of a row in one aligned 16-byte word (even first column)
+struct D2 { double v[2]; };
+__device__ __forceinline__ D2 ld2(const double *p) { const double2 t = *reinterpret_cast<const double2 *>(p); return D2{{t.x, t.y}}; }
+__device__ __forceinline__ void st2(double *p, const D2 &x) { *reinterpret_cast<double2 *>(p) = make_double2(x.v[0], x.v[1]); }
 // slab predicates for local column t
 __device__ __forceinline__ bool first_node(const Dev &d, int t) { return d.t0 + t == 0; }       // global node 0
 __device__ __forceinline__ bool last_node(const Dev &d, int t) { return d.t0 + t == d.T; }      // global node T

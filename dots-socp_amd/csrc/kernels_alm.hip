@@ -24,9 +24,6 @@ namespace dots {
 // the corner list in order: when node t + 1 belongs to the next time slab that rank forms the s = 1 half from its own
 // B and beta_mid (soc_half_of_first_node) and this one reads it from the halo -- bit for bit the same sum.
 // two consecutive time columns of a row (16-byte aligned: even column, pitch a power of two)
-struct D2 { double v[2]; };
-__device__ __forceinline__ D2 ld2(const double *p) { const double2 t = *reinterpret_cast<const double2 *>(p); return D2{{t.x, t.y}}; }
-__device__ __forceinline__ void st2(double *p, const D2 &x) { *reinterpret_cast<double2 *>(p) = make_double2(x.v[0], x.v[1]); }
 
 __device__ __forceinline__ double soc_half(const Dev &d, int v, int t, int s, double sB) {
     double acc = 0.0;

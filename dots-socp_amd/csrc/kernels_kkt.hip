@@ -198,12 +198,238 @@ __device__ __forceinline__ void kkt_triangle_body(const Dev &d, const KktArgs &a
     }
 }
 
+// ---- the same sums with TWO consecutive nodes (t, t + 1; t even) per lane, one GPU only (no halos): every array is read in the
+// column of its node or interval, so both sit in one aligned 16-byte word of the row; the corner walks load the mesh constants
+// once for both.  Half the waves for the same bytes (these launches run on the iterations the host waits for).  Element for
+// element the expressions of the bodies above; a lane adds its first node's terms, then its second's. -----------------------
+__device__ __forceinline__ void kkt_vertex_body2(const Dev &d, const KktArgs &a, int bid, int nblk, double *__restrict__ part, double *lds) {
+    constexpr int SUB = TILE_ELEMS / (2 * BLOCK);
+    const int G8 = nblk / SUB;
+    const int tile = xcd_tile(bid % G8, d.n_vtiles);
+    double s[N_VSUMS];
+#pragma unroll
+    for (int i = 0; i < N_VSUMS; ++i) s[i] = 0.0;
+    const bool c0 = a.mask & 1u, c1 = a.mask & 2u, c2 = a.mask & 4u, c3 = a.mask & 8u, c4 = a.mask & 16u, c6 = a.mask & 64u;
+    const int e = ((bid / G8) * BLOCK + threadIdx.x) * 2;
+    const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
+    if (tile < d.n_vtiles && v < d.V && t < d.nl) {
+        const double ih = 1.0 / d.h, rho_s = a.ds * a.r;
+        const int iv = idxV(d, v, t);
+        const double m = d.mass_v[v];
+        const bool has[2] = {t < d.ni, t + 1 < d.ni};          // the intervals t, t + 1 exist
+        const bool node1 = t + 1 < d.nl;                        // the second node exists
+        const D2 A = ld2(d.A + iv), mu = ld2(d.mu + iv), lc = ld2(d.lam + iv);
+        if (has[0]) {
+            D2 ph = {{0.0, 0.0}}, zf = ph, ze = ph, be = ph, bf = ph;
+            double ph2 = 0.0;
+            if (c0) { ph = ld2(d.phi + iv); if (has[1]) ph2 = d.phi[iv + 2]; }
+            if (c1) { zf = ld2(d.zf + iv); ze = ld2(d.ze + iv); }
+            if (c3) { be = ld2(d.be + iv); bf = ld2(d.bf + iv); }
+            double q[2] = {0.0, 0.0};
+            if (c4) {   // one corner walk for both intervals: B at the nodes t, t + 1, t + 2
+                for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+                    const int f = d.cidx[j] / 3;
+                    double sq[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int64_t i = idxF(d, f, c, t);
+                        const D2 b = ld2(d.B + i);
+                        const double b0 = a.ps * b.v[0], b1 = a.ps * b.v[1];
+                        sq[0] += b0 * b0 + b1 * b1;
+                        if (has[1]) {
+                            const double b2 = a.ps * d.B[i + 2];
+                            sq[1] += b1 * b1 + b2 * b2;
+                        }
+                    }
+                    const double ca = d.c_area[j];
+                    q[0] += ca * sq[0] * (1.0 / 3.0);
+                    q[1] += ca * sq[1] * (1.0 / 3.0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!has[u]) continue;
+                const double Au = A.v[u], muu = mu.v[u], lcu = lc.v[u];
+                if (c0) {
+                    const double dphi = ((u == 0 ? ph.v[1] : ph2) - ph.v[u]) * ih;
+                    const double rm = dphi - Au - lcu;
+                    s[V_DPHI2] += dphi * dphi * m;
+                    s[V_A2] += Au * Au * m;
+                    s[V_RESMU2] += rm * rm * m;
+                }
+                if (c0 || c6) s[V_LAM2] += lcu * lcu * m;
+                if (c1) {
+                    const double rf = zf.v[u] + a.sz * Au - a.cd, re = ze.v[u] - a.sz * Au - a.cd;
+                    s[V_RFST2] += rf * rf * m;
+                    s[V_REND2] += re * re * m;
+                }
+                if (c3 || c4 || c6) s[V_MU2] += muu * muu * m;
+                if (c3) {
+                    const double a1 = a.sz * (be.v[u] - bf.v[u]);
+                    s[V_AUX1_2] += a1 * a1 * m;
+                    s[V_MUAUX1_2] += (muu + a1) * (muu + a1) * m;
+                }
+                if (c4) {
+                    const double rho = rho_s * muu;
+                    const double aux = a.ps * Au + 0.25 * q[u] / m;
+                    const double res = fmax(0.0, aux + rho) - rho;
+                    s[V_COMP_AUX2] += aux * aux * m;
+                    s[V_COMP_RES2] += res * res * m;
+                }
+                if (c6) {
+                    const double res = a.cong * (rho_s * muu) - a.ps * lcu;
+                    s[V_CONG_RES2] += res * res * m;
+                }
+            }
+        }
+        if (c2) {       // Dual(alpha) at the nodes t and t + 1
+            const double mum1 = t > 0 ? d.mu[iv - 1] : 0.0;
+            double dsx[2] = {0.0, 0.0};
+            for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+                const int f = d.cidx[j] / 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double ga = d.c_gA[j * 3 + c];
+                    const D2 E = ld2(d.E + idxF(d, f, c, t));
+                    dsx[0] += ga * E.v[0];
+                    dsx[1] += ga * E.v[1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !node1) continue;
+                const int tu = t + u;
+                double x = 0.0;
+                if (tu < d.ni) x += mu.v[u] * m;
+                if (tu > 0) x -= (u == 0 ? mum1 : mu.v[0]) * m;
+                x *= ih;
+                x -= dsx[u];
+                if (tu == 0) x -= a.bs * d.mu0[v] / (a.r * d.h);
+                if (tu == d.T) x += a.bs * d.mu1[v] / (a.r * d.h);
+                const double aux = (a.r * d.h) * x / m;
+                s[V_DUALAUX2] += aux * aux * m;
+            }
+        }
+    }
+    block_sum<N_VSUMS>(s, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N_VSUMS; ++i) part[(int64_t)i * nblk + bid] = s[i];
+    }
+}
+
+__device__ __forceinline__ void kkt_triangle_body2(const Dev &d, const KktArgs &a, int bid, int nblk, double *__restrict__ part, double *lds) {
+    constexpr int SUB = TILE_ELEMS / (2 * BLOCK);
+    const int G8 = nblk / SUB;
+    const int tile = xcd_tile(bid % G8, d.n_ftiles);
+    double s[N_FSUMS];
+#pragma unroll
+    for (int i = 0; i < N_FSUMS; ++i) s[i] = 0.0;
+    const bool c0 = a.mask & 1u, c1 = a.mask & 2u, c3 = a.mask & 8u, c5 = a.mask & 32u;
+    const int e = ((bid / G8) * BLOCK + threadIdx.x) * 2;
+    const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
+    if (tile < d.n_ftiles && row < 3 * d.F && t < d.nl) {
+        const double sB = a.sz * INV_SQRT3, rho_s = a.ds * a.r;
+        const int f = row / 3, c = row - 3 * f;
+        const double w = d.area_f[f];
+        const int64_t ie = idxF(d, f, c, t);
+        const int nu = t + 1 < d.nl ? 2 : 1;                    // nodes of this lane
+        const D2 B = ld2(d.B + ie);
+        int vk[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vk[k] = d.tri[f * 3 + k];
+        D2 E = {{0.0, 0.0}}, phik[3], b0[3], b1[3], z0[3], z1[3], muk[3];
+        double mum1[3] = {0.0, 0.0, 0.0}, hk[3] = {0.0, 0.0, 0.0};
+        if (c3 || c5) E = ld2(d.E + ie);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (c0) { hk[k] = d.hat[(f * 3 + k) * 3 + c]; phik[k] = ld2(d.phi + idxV(d, vk[k], t)); }
+            if (c3) { b0[k] = ld2(d.bm + idxM(d, f * 3 + k, 0, c, t)); b1[k] = ld2(d.bm + idxM(d, f * 3 + k, 1, c, t - 1)); }
+            if (c1) { z0[k] = ld2(d.zm + idxM(d, f * 3 + k, 0, c, t)); z1[k] = ld2(d.zm + idxM(d, f * 3 + k, 1, c, t - 1)); }
+            if (c5) {
+                const int iv = idxV(d, vk[k], t);
+                muk[k] = ld2(d.mu + iv);
+                if (t > 0) mum1[k] = d.mu[iv - 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u >= nu) continue;
+            const int tu = t + u;
+            const bool has0 = tu < d.ni, has1 = tu > 0;          // the intervals tu and tu - 1 exist
+            const double Bu = B.v[u];
+            if (c0) {
+                double gx = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) gx += hk[k] * phik[k].v[u];
+                s[F_DX2 - N_VSUMS] += gx * gx * w;
+                s[F_B2 - N_VSUMS] += Bu * Bu * w;
+                s[F_RESE2 - N_VSUMS] += (gx - Bu) * (gx - Bu) * w;
+            }
+            if (c3 || c5) {
+                const double Eu = E.v[u];
+                s[F_E2 - N_VSUMS] += Eu * Eu * w;
+                if (c3) {
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (has0) s0 += b0[k].v[u];
+                        if (has1) s1 += b1[k].v[u];
+                    }
+                    const double a2 = sB * (s0 + s1);
+                    s[F_AUX2_2 - N_VSUMS] += a2 * a2 * w;
+                    s[F_EAUX2_2 - N_VSUMS] += (Eu + a2) * (Eu + a2) * w;
+                }
+                if (c5) {
+                    double rn = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        double r2 = 0.0;
+                        if (has0) r2 += muk[k].v[u];
+                        if (has1) r2 += (u == 0 ? mum1[k] : muk[k].v[0]);
+                        rn += 0.5 * rho_s * r2;
+                    }
+                    const double aux = (rn * (1.0 / 3.0)) * (a.ps * Bu);
+                    const double mm = rho_s * Eu;
+                    s[F_AUX5_2 - N_VSUMS] += aux * aux * w;
+                    s[F_AUX5M_2 - N_VSUMS] += (aux - mm) * (aux - mm) * w;
+                }
+            }
+            if (c1) {
+                const double sb = sB * Bu;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (has0) {
+                        const double q = a.sz * (z0[k].v[u] - sb);
+                        s[F_RMID2 - N_VSUMS] += q * q * w;
+                    }
+                    if (has1) {
+                        const double q = a.sz * (z1[k].v[u] - sb);
+                        s[F_RMID2 - N_VSUMS] += q * q * w;
+                    }
+                }
+            }
+        }
+    }
+    block_sum<N_FSUMS>(s, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N_FSUMS; ++i) part[(int64_t)i * nblk + bid] = s[i];
+    }
+}
+
 // Workgroups [0, nv): the vertex sums (first: their corner walks are the longer chain), [nv, nv + nf): the triangle sums.
 // One launch for both on the iterations that read residuals back (independent sums: two latency-bound kernels overlap).
+template <bool TWO>
 __global__ __launch_bounds__(BLOCK) void k_kkt_sums(Dev d, KktArgs a, int nv, double *__restrict__ part_v, double *__restrict__ part_f) {
     __shared__ double lds[(N_VSUMS > N_FSUMS ? N_VSUMS : N_FSUMS) * 4];
-    if ((int)blockIdx.x < nv) kkt_vertex_body(d, a, blockIdx.x, nv, part_v, lds);
-    else kkt_triangle_body(d, a, blockIdx.x - nv, gridDim.x - nv, part_f, lds);
+    if (TWO) {
+        if ((int)blockIdx.x < nv) kkt_vertex_body2(d, a, blockIdx.x, nv, part_v, lds);
+        else kkt_triangle_body2(d, a, blockIdx.x - nv, gridDim.x - nv, part_f, lds);
+    } else {
+        if ((int)blockIdx.x < nv) kkt_vertex_body(d, a, blockIdx.x, nv, part_v, lds);
+        else kkt_triangle_body(d, a, blockIdx.x - nv, gridDim.x - nv, part_f, lds);
+    }
 }
 
 // one workgroup per slot: scal[SUMS + first + slot] = sum_blk part[slot][blk]
@@ -290,14 +516,17 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
     const Dev &d = c->d;
     const dots_params &p = c->prm;
     KktArgs a{mask, p.r, p.scale_z, p.const_d, p.congestion, p.prim_scale, p.dual_scale, p.boundary_scale};
-    const int gv = xcd_grid(d.n_vtiles) * (TILE_ELEMS / BLOCK), gf = xcd_grid(d.n_ftiles) * (TILE_ELEMS / BLOCK);
+    const bool two = c->kkt_two && !d.slab && d.TP >= 4;      // two nodes per lane (kkt_*_body2)
+    const int per_tile = two ? TILE_ELEMS / (2 * BLOCK) : TILE_ELEMS / BLOCK;
+    const int gv = xcd_grid(d.n_vtiles) * per_tile, gf = xcd_grid(d.n_ftiles) * per_tile;
     double *part_f = d.partials + (int64_t)N_VSUMS * gv;
     const bool need_v = mask & (1u | 2u | 4u | 8u | 16u | 64u), need_f = mask & (1u | 2u | 8u | 32u);
     for (int i = 0; i < N_SUMS; ++i) sums[i] = 0.0;
     if (d.nl == 0) return 0;          // a rank without nodes contributes nothing
     const int nv = need_v ? gv : 0, nf = need_f ? gf : 0;
     if (nv + nf == 0) return 0;
-    hipLaunchKernelGGL(k_kkt_sums, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
+    if (two) hipLaunchKernelGGL(k_kkt_sums<true>, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
+    else hipLaunchKernelGGL(k_kkt_sums<false>, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
     int rc;
     if (c->spin_fetch && c->h_mail && c->kkt_counter) {
         const double seq = (double)(++c->mail_seq);
@@ -507,7 +736,7 @@ int norm_square(Ctx *c, int id, int part, double *out) {
 }
 
 void preload_kkt_kernels() {      // (see preload_alm_kernels)
-    const void *fns[] = {(const void *)k_kkt_sums, (const void *)k_reduce_slots, (const void *)k_mail_sums, (const void *)k_reduce_mail,
+    const void *fns[] = {(const void *)k_kkt_sums<true>, (const void *)k_kkt_sums<false>, (const void *)k_reduce_slots, (const void *)k_mail_sums, (const void *)k_reduce_mail,
                          (const void *)k_objective, (const void *)k_norm};
     hipFuncAttributes a;
     for (const void *f : fns) (void)hipFuncGetAttributes(&a, f);

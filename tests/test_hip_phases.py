@@ -324,3 +324,32 @@ def test_right_hand_side_ahead_is_bit_identical_and_dropped_on_changes():
     dev.step(1)
     assert np.isfinite(dev.kkt([0])[0][0])
     dev.close()
+
+
+@pytest.mark.parametrize("fixture", ["ops_ico1.npz", "ops_torus8x6.npz"])
+def test_kkt_sums_with_two_nodes_per_lane(fixture, monkeypatch):
+    """The KKT kernels take two nodes per lane on one GPU (kkt_vertex_body2 / kkt_triangle_body2); DOTS_KKT_TWO=0 keeps the one-node
+    bodies (which the time slabs use): same residuals to rounding (the sums are formed in a different order), every condition
+    alone and all together, odd and even numbers of nodes."""
+    from dots_socp_amd.device import DeviceProblem
+
+    g = golden(fixture)
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    for T in (int(g["n_time"]), int(g["n_time"]) + 1):
+        res = []
+        for two in ("0", "1"):
+            monkeypatch.setenv("DOTS_KKT_TWO", two)
+            dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+            for name in ("A", "lambda_c", "mu", "B", "E", "phi", "z_fst", "z_mid", "z_end", "beta_fst", "beta_mid", "beta_end"):
+                dev.upload(name, np.random.default_rng(sum(map(ord, name))).standard_normal(dev.shape(name)))
+            dev.set_params(r=1.3, scale_z=1.7, const_d=0.9, congestion=0.05)
+            out = [dev.kkt([i]) for i in range(7)] + [dev.kkt(range(7))]
+            res.append(out)
+            dev.close()
+        for a, b in zip(*res):
+            assert a.keys() == b.keys()
+            for i in a:
+                for x, y in zip(a[i], b[i]):
+                    assert (x is None) == (y is None)
+                    if x is not None:
+                        assert abs(x - y) <= 1e-12 * max(abs(x), 1e-300), (i, x, y)
