@@ -336,6 +336,7 @@ class AlmSolver:
         required = KKT_PRIM + KKT_DUAL if adjust else None
         validator = self.kkt_validator
 
+        history = None
         if not self.check_kkt_step_by_step:
             if adjust:
                 validator.reset_counter()
@@ -344,17 +345,13 @@ class AlmSolver:
             org, scaled = validator.collect()
             if adjust:
                 validator.reset_counter()
-            hist.record(current_it=it, kkt_errors=org)
-            error = max_of_list_with_none([org[i] for i in KKT_STOP])
-            if error is not None:
-                validator.set_error_and_tolerance(error, self.tol)
         else:
             self._kkt_prefetch(range(7))
             passed, _info = validator.validator.validate(list(range(7)))
             org, scaled = validator.collect()
             cost, lagr = self._objective()
-            hist.record(current_it=it, kkt_errors=org, history={"Transportation cost": cost, "Objective value": lagr})
-            error = max_of_list_with_none([org[i] for i in KKT_STOP])
+            history = {"Transportation cost": cost, "Objective value": lagr}
+        error = max_of_list_with_none([org[i] for i in KKT_STOP])
 
         cps = self.tol_checkpoints
         if cps and error is not None and error <= cps[0]:                      # :790-801
@@ -365,19 +362,23 @@ class AlmSolver:
             })
             cps.pop(0)
 
-        if passed or is_time_used_up or it + 1 >= self.nit:
+        stop = passed or is_time_used_up
+        if stop or it + 1 >= self.nit:
             self.finished = True
-            if passed or is_time_used_up:
-                return True
-
-        max_scaled = max_of_list_with_none(scaled)
-        if max_scaled is not None and max_scaled < 5 * self.tol:
-            self.is_org_kkt = True
-        if adjust:                                                             # :813-823
-            src = org if self.is_org_kkt else scaled
-            prim_error = max_of_list_with_none([src[i] for i in KKT_PRIM])
-            dual_error = max_of_list_with_none([src[i] for i in KKT_DUAL])
-            self.adjust_penalty(params.get_updated_value(self.r, prim_error / dual_error) / self.r)
+        if not stop:
+            max_scaled = max_of_list_with_none(scaled)
+            if max_scaled is not None and max_scaled < 5 * self.tol:
+                self.is_org_kkt = True
+            if adjust:                                                         # :813-823
+                # enqueued BEFORE the records below are written (the reference records first, :776-789): nothing the records
+                # hold depends on it, and the device divides its arrays while the host does its bookkeeping
+                src = org if self.is_org_kkt else scaled
+                prim_error = max_of_list_with_none([src[i] for i in KKT_PRIM])
+                dual_error = max_of_list_with_none([src[i] for i in KKT_DUAL])
+                self.adjust_penalty(params.get_updated_value(self.r, prim_error / dual_error) / self.r)
+        hist.record(current_it=it, kkt_errors=org, history=history)
+        if not self.check_kkt_step_by_step and error is not None:
+            validator.set_error_and_tolerance(error, self.tol)
         return self.finished
 
     # ---- final record and solution (:826-871) ------------------------------------------------
