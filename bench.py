@@ -18,7 +18,7 @@ JSON line.
   iterations that do not materialise it).
 * ``cpu_baseline``: the numpy/SuperLU oracle on the same workload on this host's cores (bounded sample).
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the iteration is sharded (dots-socp_amd/distributed.py);
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the iteration is sharded (dots_socp_amd/distributed.py);
 ``value`` is whole-job iterations/s (the iterations are collective: every rank advances the same ALM iteration),
 "scaling": "strong".
 """

@@ -1,4 +1,4 @@
-"""dots-socp_amd: MI355X-native ALM hot path of DOTs-SOCP (dynamic optimal transport on
+"""dots_socp_amd: MI355X-native ALM hot path of DOTs-SOCP (dynamic optimal transport on
 triangulated surfaces as a linear second-order-cone program).
 
 Host side (this package, Python like the reference) mirrors the reference's solver

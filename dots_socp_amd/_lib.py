@@ -147,7 +147,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m dots_socp_amd.build` (hipcc, gfx950). "
-            "dots-socp_amd has no CPU fallback."
+            "dots_socp_amd has no CPU fallback."
         )
     _torch_runtime_first()
     try:

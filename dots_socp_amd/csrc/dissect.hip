@@ -1,5 +1,5 @@
 // Host-side setup of the direct solver: geometric nested dissection of the mesh graph and the symbolic structure of
-// the multifrontal factor (no device code; the same algorithms as dots-socp_amd/frontal.py, which remains the
+// the multifrontal factor (no device code; the same algorithms as dots_socp_amd/frontal.py, which remains the
 // reference implementation for the tests).  At 10^5 vertices the Python recursion costs ~0.4 s, this ~0.03 s.
 #include "dots_dev.h"
 

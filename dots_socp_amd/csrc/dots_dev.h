@@ -112,7 +112,7 @@ struct MgDev {
     double omega = 2.0 / 3.0;
 };
 
-// Direct (multifrontal) solve of the modal problems: the factor of dots-socp_amd/frontal.py on the device.
+// Direct (multifrontal) solve of the modal problems: the factor of dots_socp_amd/frontal.py on the device.
 // F_p = [L_pp^-1 ; A_bs A_ss^-1] of node p starts at F + (foff[p] << tp_shift), entry (i, j, mode) at
 // ((i * n_p + j) << tp_shift) + mode: the mode index is fastest, as in every node array.
 struct FrontNode {            // a node of the elimination tree as the numeric factorisation sees it (kernels_factor.hip)

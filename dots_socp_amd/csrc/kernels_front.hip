@@ -1,7 +1,7 @@
 // Direct solve of the modal surface problems  (K + (sigma_a + eps) M) x_a = b_a  for all time modes a:
 // the two triangular sweeps of a multifrontal Cholesky factorisation (replaces the per-iteration
 // SuperLU solves of the reference, utils/laplacian_inverse_socp.py:46-60; the factor itself is built once
-// per solve by dots-socp_amd/frontal.py, as the reference builds its T+1 LU factors at :40-44).
+// per solve by dots_socp_amd/frontal.py, as the reference builds its T+1 LU factors at :40-44).
 //
 // One nested-dissection tree is shared by all modes.  Node p eliminates n_p separator vertices and
 // touches b_p boundary vertices of its ancestors; its dense block per mode is

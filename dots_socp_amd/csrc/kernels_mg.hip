@@ -1,7 +1,7 @@
 // Multigrid V-cycle preconditioner for the batched modal PCG (all time modes at once).
 //
 // Every time mode a solves  A_a = K + (sigma_a + eps) M  on the surface; the hierarchy (smoothed
-// aggregation on K, built on the host by dots-socp_amd/multigrid.py) is shared by all modes and each
+// aggregation on K, built on the host by dots_socp_amd/multigrid.py) is shared by all modes and each
 // level stores K_l and M_l on one sparsity pattern, so a level operator is applied to every mode in
 // one sparse-matrix x dense-block product with the mode index fastest in memory: a gathered
 // neighbour row is one contiguous run of doubles, exactly as in the PCG operator.

@@ -70,7 +70,7 @@ enum dots_lap_solver {
 /*
  * Problem description: the outputs of the reference's operator assembly
  * (utils/surface_pre_computations_socp.py:11-132, solver_socp.py:102-113,161-192) as flat arrays.
- * The host side (dots-socp_amd/geometry.py) builds them; all index arrays are 0-based int32.
+ * The host side (dots_socp_amd/geometry.py) builds them; all index arrays are 0-based int32.
  */
 typedef struct dots_problem_desc {
     int32_t abi_version;     /* DOTS_ABI_VERSION */
@@ -280,7 +280,7 @@ int dots_apply_operator(dots_ctx *ctx, int op, double scale, const double *in, i
 
 /* ---- multigrid preconditioner of the modal PCG (optional; Jacobi is used without it) ----------
  * Smoothed-aggregation hierarchy of the surface stiffness matrix, built on the host
- * (dots-socp_amd/multigrid.py).  Level l holds K_l and M_l on one CSR pattern, the prolongation P_l
+ * (dots_socp_amd/multigrid.py).  Level l holds K_l and M_l on one CSR pattern, the prolongation P_l
  * (n_l x n_{l+1}) and its transpose; level 0 is the context's own K and vertex mass (pass NULL for
  * its rowptr/col/val_k/val_m).  coarse_inverse is (K_L + (sigma_a + eps) M_L)^-1 for every mode a,
  * stored [n_L][n_L][n_cols] (pseudo-inverse for a singular mode): it depends on eps, so call
@@ -325,7 +325,7 @@ int dots_mg_enable(dots_ctx *ctx, int on);   /* switch between multigrid (1) and
 /* ---- direct solve of the modal problems (replaces the T+1 SuperLU factorisations of
  * laplacian_inverse_socp.py:40-61 and their per-iteration triangular solves, :46-60) ----------------
  * Multifrontal Cholesky factor on one nested-dissection tree shared by all modes, built on the host
- * (dots-socp_amd/frontal.py).  Nodes are numbered children-before-parents.  Node p eliminates n[p]
+ * (dots_socp_amd/frontal.py).  Nodes are numbered children-before-parents.  Node p eliminates n[p]
  * separator vertices and touches b[p] boundary vertices of its ancestors; front_idx lists them
  * (separator first) from ioff[p]; its dense block F_p = [L_pp^-1 ; A_bs A_ss^-1], (n+b) x n per mode,
  * starts at row foff[p] of `values` ([n_entries][pitch], mode fastest).  pull0/pull1 (parallel to
@@ -368,7 +368,7 @@ typedef struct dots_front_desc {
 int dots_front_setup(dots_ctx *ctx, const dots_front_desc *desc);
 
 /* Host-side helpers for dots_front_desc (no device work; the Python reference implementations are in
- * dots-socp_amd/frontal.py).
+ * dots_socp_amd/frontal.py).
  * dots_tree_build: geometric nested dissection of the graph (CSR pattern of K, 0-based) of `n_vertices` points
  * `xyz` [V][3]: subsets are cut at the median of their longest bounding-box side (principal axis above 512
  * vertices), the separator is the smaller one-sided vertex boundary of the cut, subsets of <= `leaf` vertices

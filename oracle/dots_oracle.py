@@ -4,7 +4,7 @@ A plain numpy / scipy.sparse restatement of the reference algorithm
 (`/root/reference/dot_surface_socp/socp/solver_socp.py:25-1065` and the files it
 calls).  It exists to *check* the HIP path, never to serve it: only ``tests/``,
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
-import this module.  Nothing under ``dots-socp_amd/`` imports it.
+import this module.  Nothing under ``dots_socp_amd/`` imports it.
 
 Parity status: PINNED.  ``tests/golden/*.npz`` hold input/output vectors recorded
 from the reference itself in the build container (``tests/golden/make_golden.py``

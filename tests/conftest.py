@@ -37,7 +37,7 @@ def has_gpu():
         return False
 
 
-# torch's bundled HIP runtime must be the one the process binds (dots-socp_amd/_lib.py: _torch_runtime_first): load and
+# torch's bundled HIP runtime must be the one the process binds (dots_socp_amd/_lib.py: _torch_runtime_first): load and
 # initialise torch before the product library, whatever test file runs first.
 if has_gpu():
     import torch

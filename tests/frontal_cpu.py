@@ -1,5 +1,5 @@
 """numpy restatement of the two sweeps of the device's multifrontal solve (csrc/kernels_front.hip), reading the
-same flat arrays (dots-socp_amd/frontal.py:FrontalFactor).  TEST INFRASTRUCTURE: validates the host-side
+same flat arrays (dots_socp_amd/frontal.py:FrontalFactor).  TEST INFRASTRUCTURE: validates the host-side
 factorisation against scipy on CPU and stands in for the device in the gloo tests; the product has no CPU path."""
 import numpy as np
 

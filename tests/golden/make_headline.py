@@ -4,7 +4,7 @@
     python tests/golden/make_headline.py oracle torus100k                    # the CPU oracle (the reference would
                                                                               # need hours at this size)
 
-Geometry comes from dots-socp_amd/meshes.py (deterministic generators), so a fixture stores
+Geometry comes from dots_socp_amd/meshes.py (deterministic generators), so a fixture stores
 only a checksum of it, the stopping iteration, the cost / objective / KKT histories and a sample of the solution
 (every 40th vertex of mu, plus per-layer sums and norms): ``headline_<workload>.npz``."""
 from __future__ import annotations

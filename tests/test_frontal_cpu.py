@@ -1,4 +1,4 @@
-"""CPU tests of the host side of the direct solver (dots-socp_amd/frontal.py): the nested-dissection tree,
+"""CPU tests of the host side of the direct solver (dots_socp_amd/frontal.py): the nested-dissection tree,
 the symbolic structure and the batched multifrontal factor, checked by running the device's sweeps in numpy
 (tests/frontal_cpu.py) against scipy's sparse solve."""
 import numpy as np

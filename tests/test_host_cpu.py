@@ -64,7 +64,7 @@ def test_no_silent_cpu_fallback():
 
 
 def test_product_never_imports_the_oracle():
-    pkg = os.path.join(ROOT, "dots-socp_amd")
+    pkg = os.path.join(ROOT, "dots_socp_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h")):
@@ -250,7 +250,7 @@ def test_mesh_generators():
 
 
 def test_evaluate_helpers_match_the_reference_outputs():
-    """dots-socp_amd/evaluate.py against the outputs of the reference's utils/evaluate_solution.py:7-58 (and its
+    """dots_socp_amd/evaluate.py against the outputs of the reference's utils/evaluate_solution.py:7-58 (and its
     utils/util.py:32-67 norms) recorded by tests/golden/make_golden.py f1 on two recorded solutions."""
     from dots_socp_amd import evaluate, meshes
 
@@ -286,7 +286,7 @@ def test_plane_exact_transport_matches_the_reference():
 
 
 def test_example_settings_match_the_reference_get_mu():
-    """dots-socp_amd/examples.py against get_mu of every data/settings/*.py (recorded on synthetic meshes)."""
+    """dots_socp_amd/examples.py against get_mu of every data/settings/*.py (recorded on synthetic meshes)."""
     from dots_socp_amd import examples
 
     g = np.load(os.path.join(GOLDEN_DIR, "settings_get_mu.npz"))

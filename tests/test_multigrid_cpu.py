@@ -1,4 +1,4 @@
-"""CPU tests of the host-side multigrid setup (dots-socp_amd/multigrid.py): hierarchy invariants, the
+"""CPU tests of the host-side multigrid setup (dots_socp_amd/multigrid.py): hierarchy invariants, the
 three-kernel form of the V-cycle the device uses, and its quality as a PCG preconditioner."""
 import numpy as np
 import pytest
