@@ -18,9 +18,14 @@ JSON line.
   iterations that do not materialise it).
 * ``cpu_baseline``: the numpy/SuperLU oracle on the same workload on this host's cores (bounded sample).
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the iteration is sharded (dots_socp_amd/distributed.py);
-``value`` is whole-job iterations/s (the iterations are collective: every rank advances the same ALM iteration),
-"scaling": "strong".
+For N > 1 the iteration is sharded over time slabs (dots_socp_amd/distributed.py), one rank per GPU over RCCL.  Started as
+``python bench.py --gpus N`` the script launches its N ranks itself (torch.distributed.run, before anything touches the GPU) and
+relays rank 0's line and the ranks' exit code; started by torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.  ``value``
+is whole-job iterations/s of the metric's configuration (the iterations are collective: every rank advances the same ALM
+iteration), "scaling": "strong"; ``sharded_configs`` times the configurations BASELINE.json places on several GPUs
+(torus100k: configs[3], torus65k_T127: configs[4]) on the same ranks: steady it/s, exchange seconds, per-rank device bytes, a
+run to tol.  With fewer GPUs than ranks (a one-GPU box) the ranks share the GPUs over gloo (a rehearsal of the command, not a
+scaling measurement; DOTS_DIST_BACKEND overrides).
 """
 from __future__ import annotations
 
@@ -53,6 +58,7 @@ WORKLOADS = {
     "plane20": dict(example="plane", kw=dict(n=20), n_time=31, congestion=0.0, tol=1e-3, config=None),
 }
 ALL_CONFIGS = ["knot", "sphere10k", "knot63", "torus100k", "torus65k_T127"]
+SHARDED_CONFIGS = ["torus100k", "torus65k_T127"]      # the configurations BASELINE.json places on 4 and 8 GPUs
 STEADY = {"torus65k_T127": (40, 100), "torus100k": (100, 200), "torus500k": (20, 40)}     # (first timed iteration, timed iterations); default (100, 200)
 
 
@@ -69,7 +75,9 @@ def parse():
     ap.add_argument("--nd-leaf", type=int, default=None, help="leaf size of the nested dissection (default: solver default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-time-to-tol", action="store_true")
-    ap.add_argument("--no-configs", action="store_true", help="skip the table of the five BASELINE configurations")
+    ap.add_argument("--no-configs", action="store_true", help="skip the table of the five BASELINE configurations (N > 1: the sharded ones)")
+    ap.add_argument("--no-alternatives", action="store_true", help="skip the PCG alternatives of the Laplacian solve on torus100k")
+    ap.add_argument("--tol-seconds", type=float, default=150.0, help="wall-clock cap of a sharded run to tol")
     ap.add_argument("--no-reorder", action="store_true", help="keep the generator's vertex numbering (A/B of the renumbering)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget of the cpu_baseline sample")
     return ap.parse_args()
@@ -176,25 +184,26 @@ class Timer:
         self.barrier()
         el = time.perf_counter() - t0
         if self.dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if self.dist.get_backend() == "nccl" else "cpu")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             el = float(t.item())
         return el
 
 
-def build_solver(args, wl, geom, nit, local_rank, world, tol=1e-30, time_limit=float("inf")):
+def build_solver(args, wl, geom, nit, local_rank, world, tol=1e-30, time_limit=float("inf"), lap_solver=None, preconditioner=None):
     from dots_socp_amd.socp.solver_socp import AlmSolver, DEFAULT_CG_TOL
 
     cg_tol = args.cg_tol if args.cg_tol is not None else DEFAULT_CG_TOL
     kw = {} if args.mg_coarsest is None else {"mg_coarsest": args.mg_coarsest}
     if args.nd_leaf is not None:
         kw["nd_leaf"] = args.nd_leaf
-    common = dict(congestion=wl["congestion"], nit=nit, tol=tol, cg_tol=cg_tol, device=local_rank, preconditioner=args.preconditioner,
-                  lap_solver=args.lap_solver, time_limit=time_limit, reorder=not args.no_reorder, **kw)
+    lap_solver = lap_solver or args.lap_solver
+    common = dict(congestion=wl["congestion"], nit=nit, tol=tol, cg_tol=cg_tol, device=local_rank, preconditioner=preconditioner or args.preconditioner,
+                  lap_solver=lap_solver, time_limit=time_limit, reorder=not args.no_reorder, **kw)
     if world > 1:
         from dots_socp_amd.distributed import ShardedAlmSolver, TorchComm
 
-        if args.lap_solver == "spacetime_pcg":
+        if lap_solver == "spacetime_pcg":
             raise SystemExit("--gpus N>1 shards the time modes: use --lap-solver modal_direct or modal_pcg")
         return ShardedAlmSolver(wl["n_time"], geom, comm=TorchComm(), **common)
     return AlmSolver(wl["n_time"], geom, **common)
@@ -286,23 +295,158 @@ def config_entry(args, name, local_rank):
     return entry
 
 
+def gather_ints(dist, value):
+    """``value`` of every rank (a list on every rank)."""
+    import torch
+
+    if dist is None:
+        return [int(value)]
+    t = torch.tensor([int(value)], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    out = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return [int(x) for x in out.cpu()]
+
+
+def sharded_entry(args, name, local_rank, world, dist):
+    """One multi-GPU configuration of BASELINE.json on the ranks of this job: steady-state rate (barriers, max over ranks), what
+    the exchanges cost, per-rank device memory, and a run to the configuration's tol (capped at --tol-seconds)."""
+    from dots_socp_amd import meshes
+    from dots_socp_amd.distributed import ShardedAlmSolver
+
+    wl = WORKLOADS[name]
+    geom, _ = meshes.example(wl["example"], **wl["kw"])
+    V, F, T = geom["vertices"].shape[0], geom["triangles"].shape[0], wl["n_time"]
+    first, count = STEADY.get(name, (100, 200))
+    t0 = time.perf_counter()
+    alm = build_solver(args, wl, geom, first + count + 8, local_rank, world)
+    setup_s = time.perf_counter() - t0
+    tm = Timer(alm, dist)
+    for _ in range(first):
+        alm.iterate()
+    comm0 = dict(alm.comm.bytes)
+    el = tm.run(count)
+    alm._collect_step_times(wait=True)
+    sent = {k: alm.comm.bytes[k] - comm0[k] for k in comm0}
+    entry = {
+        "workload": name, "baseline_config": wl["config"], "V": V, "F": F, "ntime": T, "congestion": wl["congestion"], "tol": wl["tol"],
+        "ranks": world, "nodes_per_rank": alm.dev.slab[2], "iterations_per_s": count / el, "ms_per_step": 1e3 * el / count,
+        "window": f"iterations {first}..{first + count - 1}", "setup_seconds": setup_s,
+        "step_seconds_estimated_for_all_iterations": dict(alm.run_history.steps_time),
+        "exchange_seconds_per_iteration": alm.run_history.steps_time.get(ShardedAlmSolver.EXCHANGE_TAG, 0.0) / max(alm.counter_main + 1, 1),
+        "bytes_handed_to_collectives_per_iteration_rank0": {k: v / count for k, v in sent.items() if v},
+        "device_bytes_per_rank": gather_ints(dist, alm.dev.device_bytes()),
+    }
+    alm.close()
+    if not args.no_time_to_tol:
+        t1 = time.perf_counter()
+        solver = build_solver(args, wl, geom, 20000, local_rank, world, tol=wl["tol"], time_limit=args.tol_seconds)
+        setup_s = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        while not solver.iterate():
+            pass
+        _, hist = solver.finalize(download=False)
+        solve_s = time.perf_counter() - t1
+        max_kkt = float(max(hist.kkt_errors[-1]))
+        entry["time_to_tol"] = {"tol": wl["tol"], "seconds": solve_s, "setup_seconds": setup_s, "iterations": int(hist.kkt_iteration[-1]) + 1,
+                                "transport_cost": float(hist.history["Transportation cost"][-1]), "max_kkt": max_kkt,
+                                "reached_tol": bool(max_kkt < wl["tol"]), "wall_clock_cap_seconds": args.tol_seconds}
+        solver.close()
+    return entry
+
+
+def solver_alternatives(args, local_rank, name="torus100k", budget_s=20.0):
+    """The north star's named solvers of step 1 beside the direct one, on the ~100k-vertex configuration, N = 1: the batched
+    multigrid-PCG on the time modes and the Jacobi-PCG on the assembled space-time operator (CSR row blocks staged in LDS):
+    ALM it/s, PCG iterations per step, and the hipEvent-timed bandwidth of the operator application k_cg_apply."""
+    from dots_socp_amd import meshes
+
+    wl = WORKLOADS[name]
+    geom, _ = meshes.example(wl["example"], **wl["kw"])
+    V, T = geom["vertices"].shape[0], wl["n_time"]
+    out = []
+    for lap, pre, warm, count in (("modal_pcg", "multigrid", 20, 30), ("spacetime_pcg", "jacobi", 10, 10)):
+        t0 = time.perf_counter()
+        alm = build_solver(args, wl, geom, warm + count + 8, local_rank, 1, lap_solver=lap, preconditioner=pre)
+        tm = Timer(alm, None)
+        for _ in range(warm):
+            alm.iterate()
+        cg0 = alm.cg_total
+        el = tm.run(count)
+        roof, _ = solve_roofline(alm, V, T)
+        out.append({"workload": name, "lap_solver": lap, "preconditioner": pre, "iterations_per_s": count / el, "ms_per_step": 1e3 * el / count,
+                    "window": f"iterations {warm}..{warm + count - 1}", "pcg_iterations_per_step": (alm.cg_total - cg0) / count,
+                    "pcg_not_converged": int(alm.cg_fail), "cg_tol": alm.dev.params.cg_tol,
+                    "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "ms_per_launch",
+                                                      "algorithmic_bytes_per_launch") if k in roof},
+                    "seconds_spent": time.perf_counter() - t0})
+        alm.close()
+        if time.perf_counter() - t0 > budget_s:
+            break
+    return out
+
+
+def traffic_record(workload):
+    """PMC traffic of one solve (roofline.traffic).  Counters cannot be read inside this process: the figure is the one the
+    rocprofv3 --pmc passes of THIS command recorded (profiles/tools/collect_traffic.sh).  It is stamped with the hash of the
+    sweep kernels' sources it was measured on and dropped (traffic = null) when they have changed since."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    if not os.path.exists(path):
+        return None, "no recorded PMC passes for this workload"
+    with open(path) as fh:
+        tr = json.load(fh)
+    now = kernel_digest()
+    src = tr["source"] + "; NOT measured in this run"
+    if tr.get("kernel_sources_sha256") != now:
+        return None, src + f"; STALE: the sweep kernels changed since (recorded {str(tr.get('kernel_sources_sha256'))[:12]}, now {now[:12]}): traffic withheld"
+    return tr["bytes_per_solve"], src
+
+
+def kernel_digest():
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("kernels_front.hip", "kernels_factor.hip", "dots_dev.h"):
+        with open(os.path.join(ROOT, "dots_socp_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks (one per GPU) before anything in this process touches
+    the GPU, let rank 0's JSON line through, return the ranks' exit code."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
     import torch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    # one rank per GPU; DOTS_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)
-    backend = os.environ.get("DOTS_DIST_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count()
+    # one rank per GPU over RCCL; with fewer GPUs than ranks (a one-GPU box) the ranks share the GPUs and exchange over gloo:
+    # RCCL refuses two ranks on one device.  DOTS_DIST_BACKEND overrides.
+    from dots_socp_amd._lib import env_choice
+
+    n_dev = torch.cuda.device_count()
+    backend = env_choice("DOTS_DIST_BACKEND", ("nccl", "gloo"), "nccl" if n_dev >= world else "gloo")
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
 
     from dots_socp_amd import meshes
@@ -332,7 +476,6 @@ def main():
     cg0 = alm.cg_total
     elapsed = tm.run(args.steps)                                   # the driver's K steps after W warm-up steps
     cg_per_it = (alm.cg_total - cg0) / max(args.steps, 1)
-    steps_time = dict(alm.run_history.steps_time)
     done = args.warmup + args.steps
     for _ in range(max(0, steady_first - done)):
         alm.iterate()
@@ -348,15 +491,14 @@ def main():
     # under rocprofv3 --pmc (profiles/tools/pmc_summary.py); a single launch, outside the timed region
     _, calib_bytes = alm.dev.bench_kernel(which=4, reps=1)
     roofline["pmc_calibration_bytes_each_way"] = calib_bytes
-    traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-    if world == 1 and args.lap_solver == "modal_direct" and os.path.exists(traffic_file):
-        with open(traffic_file) as fh:
-            tr = json.load(fh)
-        # PMC counters cannot be read inside this process: the figure comes from the rocprofv3 --pmc passes of THIS command
-        # recorded by profiles/tools/collect_traffic.sh; traffic_source names the commit it was measured on
-        roofline["traffic"] = tr["bytes_per_solve"]
-        roofline["traffic_source"] = tr["source"]
+    if world == 1 and args.lap_solver == "modal_direct":
+        roofline["traffic"], roofline["traffic_source"] = traffic_record(args.workload)
+    roofline["kernel_sources_sha256"] = kernel_digest()
     dev_bytes = alm.dev.device_bytes()
+    dev_bytes_ranks = gather_ints(dist, dev_bytes)
+    alm._collect_step_times(wait=True)
+    steps_time_all = dict(alm.run_history.steps_time)
+    steps_note = alm.run_history.steps_time_note
     alm.close()
 
     extra = {}
@@ -377,6 +519,10 @@ def main():
             else:
                 table.append(config_entry(args, name, local_rank))
         extra["configs"] = table
+    if rank == 0 and world == 1 and not args.no_alternatives and not args.no_configs and args.lap_solver == "modal_direct":
+        extra["solver_alternatives"] = solver_alternatives(args, local_rank)
+    if world > 1 and not args.no_configs and args.lap_solver == "modal_direct":      # collective: every rank takes part
+        extra["sharded_configs"] = [sharded_entry(args, name, local_rank, world, dist) for name in SHARDED_CONFIGS]
 
     if rank != 0:
         if dist is not None:
@@ -392,7 +538,10 @@ def main():
                         + ("" if args.lap_solver == "modal_direct" else f", preconditioner={args.preconditioner}"),
             "baseline_config": wl["config"],
             "unknowns": V * (n_time + 1), "state_bytes": 8 * ((n_time + 1) * V + 7 * n_time * V + 6 * (n_time + 1) * F + 36 * n_time * F),
-            "device_bytes": dev_bytes, "pcg_iterations_per_step": cg_per_it, "step_seconds": steps_time, "commit": git_commit(),
+            "device_bytes": dev_bytes, "device_bytes_per_rank": dev_bytes_ranks, "pcg_iterations_per_step": cg_per_it,
+            "step_seconds": steps_time_all, "step_seconds_note": steps_note, "commit": git_commit(),
+            "world_size": world, "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
+            "gpus_visible": n_dev,
         },
         "steady_state": {"iterations_per_s": steady_count / steady_el, "ms_per_step": steady_ms,
                          "window": f"iterations {steady_from}..{steady_from + steady_count - 1}"},

@@ -10,7 +10,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libdotsocp_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ARRAY_IDS = {
     "phi": 0, "A": 1, "B": 2, "lambda_c": 3, "z_fst": 4, "z_mid": 5, "z_end": 6,
@@ -18,7 +18,7 @@ ARRAY_IDS = {
 }
 LAP_SOLVERS = {"spacetime_pcg": 0, "modal_pcg": 1}
 PHASES = {"laplacian": 0, "soc_projection": 1, "q_lambda_mult": 2, "q_lambda": 3}
-STEP_SKIP_Z_MID, STEP_PALM, STEP_RHS_AHEAD = 1, 2, 4
+STEP_SKIP_Z_MID, STEP_PALM, STEP_RHS_AHEAD, STEP_TIMED = 1, 2, 4, 8
 OPERATORS = {
     "grad_time": 0, "div_time": 1, "grad_space": 2, "div_space": 3, "decouple": 4,
     "decouple_adjoint": 5, "time_avg_adjoint": 6, "laplacian_apply": 7,
@@ -28,8 +28,8 @@ EXPORTS = [
     "dots_sync", "dots_upload", "dots_download", "dots_array_count", "dots_step", "dots_run_phase", "dots_kkt",
     "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
-    "dots_slab_elems", "dots_slab_set_buffers", "dots_slab_stage", "dots_kkt_sums", "dots_kkt_combine", "dots_objective_sums",
-    "dots_objective_combine", "dots_front_launches", "dots_front_info", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
+    "dots_slab_elems", "dots_slab_set_buffers", "dots_slab_stage", "dots_kkt_sums", "dots_kkt_sums_device", "dots_debug_counter", "dots_kkt_combine", "dots_objective_sums",
+    "dots_objective_combine", "dots_front_launches", "dots_front_info", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_step_times", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
     "dots_symbolic_build", "dots_symbolic_front_rows", "dots_symbolic_copy", "dots_symbolic_free",
 ]
 
@@ -116,6 +116,43 @@ KKT_N_SUMS = 24
 SLAB_SIZES = {"vertex_halo": 0, "b_chunk": 1, "x_chunk": 2, "triangle_halo": 3}
 
 
+# Every DOTS_* environment switch the package reads (INTEGRATION.md has the table).  They are measurement aids; a name that is
+# not in this list, or a value outside a switch's domain, is an error: a typo must not silently select the default.
+KNOWN_ENV = {
+    # read by the library (csrc/dots_api.hip: env_int)
+    "DOTS_CG_STAGE_LDS", "DOTS_MG_TAIL_ROWS", "DOTS_SOC_WITH_RHS", "DOTS_QL_TWO", "DOTS_KKT_TWO", "DOTS_RHS_TWO", "DOTS_SPIN_FETCH",
+    "DOTS_FRONT_VEC2", "DOTS_FRONT_RB", "DOTS_FRONT_ROWS", "DOTS_FRONT_XCD", "DOTS_FRONT_TUNE", "DOTS_FRONT_CFG", "DOTS_MAIL_TEST_DROP",
+    "DOTS_MAIL_SPINS", "DOTS_ND_PCA_MIN",
+    # read by the host side
+    "DOTS_RHS_AHEAD", "DOTS_TIME_EVERY", "DOTS_FRONT_BANDS", "DOTS_FRONT_TOPINV", "DOTS_TORCH_FIRST", "DOTS_DIST_BACKEND", "DOTS_HIPCC_FLAGS",
+}
+
+
+def check_environment():
+    unknown = sorted(k for k in os.environ if k.startswith("DOTS_") and k not in KNOWN_ENV)
+    if unknown:
+        raise HipLibraryError(f"unknown DOTS_* environment switch(es) {unknown}; known: {sorted(KNOWN_ENV)}")
+
+
+def env_choice(name, choices, default, integer=None):
+    """The value of switch ``name``: one of ``choices`` (strings), or with ``integer=(lo, hi)`` an integer in that range
+    (returned as a string).  Unset: ``default``.  Anything else raises."""
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    if integer is not None:
+        try:
+            ok = integer[0] <= int(v) <= integer[1]
+        except ValueError:
+            ok = False
+        if not ok:
+            raise HipLibraryError(f"environment: {name}={v!r} is not an integer in [{integer[0]}, {integer[1]}]")
+        return v
+    if v not in choices:
+        raise HipLibraryError(f"environment: {name}={v!r} is not one of {list(choices)}")
+    return v
+
+
 def library_path() -> str:
     return LIB_PATH
 
@@ -125,11 +162,15 @@ def _torch_runtime_first():
     links against, so a process ends up with ONE runtime: whichever copy is loaded first.  Loaded after torch, this library
     runs on torch's copy (streams, events and device pointers are then interchangeable between the two, which distributed.py
     relies on); loaded BEFORE torch, the system copy is bound and torch's own build fails on it with "No HIP GPUs are
-    available" (measured: ROCm 7.2 system runtime, torch 2.10+rocm7.0).  If torch is already imported, initialise it here; a
-    process that imports torch only later must do that before it loads this library."""
+    available" (measured: ROCm 7.2 system runtime, torch 2.10+rocm7.0).  So torch goes first: if it is installed but not yet
+    imported it is imported (and initialised) here, whatever order the caller's own imports have (DOTS_TORCH_FIRST=0: leave a
+    torch that is not imported yet alone -- for processes that never use torch on the GPU)."""
+    import importlib.util
     import sys
 
     torch = sys.modules.get("torch")
+    if torch is None and env_choice("DOTS_TORCH_FIRST", ("0", "1"), "1") == "1" and importlib.util.find_spec("torch") is not None:
+        import torch
     if torch is None:
         return
     try:
@@ -144,6 +185,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    check_environment()
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m dots_socp_amd.build` (hipcc, gfx950). "
@@ -184,6 +226,9 @@ def load():
     lib.dots_slab_set_buffers.argtypes = [vp, C.POINTER(SlabBuffers)]
     lib.dots_slab_stage.argtypes = [vp, C.c_int, C.POINTER(StepStats)]
     lib.dots_kkt_sums.argtypes = [vp, C.c_uint32, _f64p]
+    lib.dots_kkt_sums_device.argtypes = [vp, C.c_uint32, vp]
+    lib.dots_debug_counter.argtypes = [vp, C.c_int]
+    lib.dots_debug_counter.restype = C.c_int64
     lib.dots_kkt_combine.argtypes = [vp, C.c_uint32, _f64p, _f64p]
     lib.dots_objective_sums.argtypes = [vp, _f64p]
     lib.dots_objective_combine.argtypes = [vp, _f64p, _f64p]
@@ -195,6 +240,7 @@ def load():
     lib.dots_front_launches.argtypes = [vp]
     lib.dots_front_info.argtypes = [vp, _f64p]
     lib.dots_step_flags.argtypes = [vp, C.c_uint32]
+    lib.dots_step_times.argtypes = [vp, C.POINTER(StepStats), C.c_int, C.c_int, C.POINTER(C.c_int)]
     lib.dots_stream_wait.argtypes = [vp, vp, C.c_int]
     i64p = C.POINTER(C.c_int64)
     lib.dots_tree_build.argtypes = [C.c_int32, _i32p, _i32p, _f64p, C.c_int32, C.POINTER(vp)]
@@ -213,7 +259,7 @@ def load():
     lib.dots_device_bytes.restype = C.c_int64
     for n in EXPORTS:
         f = getattr(lib, n)
-        if n not in ("dots_last_error", "dots_array_count", "dots_device_bytes", "dots_slab_elems", "dots_tree_nodes", "dots_tree_free",
+        if n not in ("dots_last_error", "dots_array_count", "dots_device_bytes", "dots_slab_elems", "dots_tree_nodes", "dots_tree_free", "dots_debug_counter",
                      "dots_symbolic_front_rows", "dots_symbolic_free"):
             f.restype = C.c_int
     if lib.dots_abi_version() != ABI_VERSION:

@@ -278,6 +278,8 @@ class RunningHistory:
     def add_time(self, tag, seconds):
         self.steps_time[tag] = self.steps_time.get(tag, 0.0) + seconds
 
+    steps_time_note = None      # how steps_time was obtained when it is not a plain sum of timers (SampledStepTimers)
+
     def record(self, current_it=None, kkt_errors=None, history=None):
         if kkt_errors is None or current_it is None:
             raise ValueError("Argument `kkt_errors` or `current_it` must be provided.")
@@ -331,6 +333,8 @@ class RunningHistory:
         lines.append(f"{tag_step_time.ljust(width)}: {s:>7.2f} sec ({100.0 * s / total_time:5.2f}%) ({100.0 * s / max(total_it, 1):<5.2f} sec/100-iterations)")
         lines.append(f"{tag_total_time.ljust(width)}: {total_time:>7.2f} sec ({100.0:5.2f}%)")
         lines.append(f"{tag_total_iteration.ljust(width)}: {total_it:>7.0f} iterations")
+        if self.steps_time_note:
+            lines.append(f"({self.steps_time_note})")
         logging.getLogger().info("\n".join(lines))
 
     def show_kkt_errors(self, filename=None, is_show_when_save=False, x_axis="iteration", title=None, x_label=None, y_label=None):
@@ -364,3 +368,54 @@ def safe_rescale_ratio(prim_gap: float, kkt_row) -> float:
     num, den = float(kkt_row[1]), float(kkt_row[0])
     q = num / den if den != 0.0 else (float("inf") if num > 0 else float("nan"))
     return prim_gap * math.sqrt(q) if q >= 0.0 else float("nan")
+
+
+class SampledStepTimers:
+    """``RunningHistory.steps_time`` (the reference's per-step timers, utils/admm_tools.py:244-251, printed as "Time of steps"
+    at :505-540 and scraped into the paper's Time[s] column by replication/log2table.py:99-106) for a loop that never waits for
+    the device: the phases of SAMPLED iterations are bracketed by events on the stream (DOTS_STEP_TIMED) and collected at
+    the next read-back.  Iterations come in kinds (e.g. "quiet": nothing read back, z_mid not stored; "read-back") that cost
+    differently; the time of a step is estimated as
+
+        sum over kinds of  (mean of the sampled iterations of the kind)  x  (iterations of the kind)
+
+    so its sum is the device time of ALL iterations' steps, not of the sampled ones.  The first ``first`` iterations of a kind
+    and every ``every``-th afterwards are sampled (``every = 1``: all of them, the estimate is then the plain sum)."""
+
+    def __init__(self, history, first=4, every=8):
+        self.history, self.first, self.every = history, int(first), max(1, int(every))
+        self.n = {}          # kind -> iterations so far
+        self.sums = {}       # kind -> tag -> [seconds, samples]
+        self.tags = []
+
+    def begin(self, kind):
+        """Count one iteration of ``kind``; True if it is to be sampled."""
+        n = self.n[kind] = self.n.get(kind, 0) + 1
+        return n <= self.first or n % self.every == 0
+
+    def add(self, kind, tag, seconds, samples=1):
+        if tag not in self.tags:
+            self.tags.append(tag)
+        acc = self.sums.setdefault(kind, {}).setdefault(tag, [0.0, 0])
+        acc[0] += seconds
+        acc[1] += samples
+
+    def publish(self):
+        hist = self.history
+        sampled = total = 0
+        for tag in self.tags:
+            est = 0.0
+            for kind, n in self.n.items():
+                acc = self.sums.get(kind, {}).get(tag)
+                if acc and acc[1]:
+                    est += acc[0] / acc[1] * n
+            hist.steps_time[tag] = est
+        for kind, n in self.n.items():
+            total += n
+            sampled += max([a[1] for a in self.sums.get(kind, {}).values()] or [0])
+        if sampled < total:
+            hist.steps_time_note = (f"device time of all {total} iterations, estimated per kind of iteration "
+                                    f"({', '.join(f'{n} {k}' for k, n in self.n.items())}) from {sampled} sampled ones: events on the "
+                                    "stream, read after the fact, no host wait in the loop")
+        else:
+            hist.steps_time_note = None

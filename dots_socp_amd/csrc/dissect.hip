@@ -174,7 +174,7 @@ int dots_tree_build(int32_t n_vertices, const int32_t *indptr, const int32_t *in
     t->sep_ptr.push_back(0);
     Dissector d{};
     d.V = n_vertices; d.leaf = leaf; d.indptr = indptr; d.indices = indices; d.xyz = xyz; d.out = t;
-    if (const char *e = getenv("DOTS_ND_PCA_MIN")) d.pca_min = atoi(e);
+    if (!dots::env_int("DOTS_ND_PCA_MIN", 0, 1 << 30, &d.pca_min)) { delete t; return DOTS_ERR_ARGUMENT; }
     d.work.resize((size_t)n_vertices);
     std::iota(d.work.begin(), d.work.end(), 0);
     d.mark.assign((size_t)n_vertices, 0);

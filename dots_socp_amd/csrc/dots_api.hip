@@ -24,6 +24,22 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     return DOTS_ERR_HIP;
 }
 
+// An integer switch from the environment: unset keeps *out; anything that is not an integer in [lo, hi] is an error.
+bool env_int(const char *name, int lo, int hi, int *out) {
+    const char *e = getenv(name);
+    if (!e) return true;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || *end != '\0' || v < lo || v > hi) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "environment: %s=%s is not an integer in [%d, %d]", name, e, lo, hi);
+        set_error(buf);
+        return false;
+    }
+    *out = (int)v;
+    return true;
+}
+
 int array_kind(int id) {
     switch (id) {
         case DOTS_PHI: return 0;
@@ -313,8 +329,22 @@ static int slab_stage(Ctx *c, int stage) {
     }
 }
 
+// a free slot of the timing ring (its events created on first use), or nullptr when the ring is full: the step is then not timed
+static hipEvent_t *time_slot(Ctx *c, int kind) {
+    if (!c->step_timed || c->t_count >= Ctx::TIME_SLOTS) return nullptr;
+    const int s = (c->t_head + c->t_count) % Ctx::TIME_SLOTS;
+    for (auto &e : c->tev[s])
+        if (!e && hipEventCreate(&e) != hipSuccess) return nullptr;
+    c->tkind[s] = kind;
+    c->t_count += 1;
+    return c->tev[s];
+}
+
 static int run_iteration(Ctx *c, dots_step_stats *st) {
     int rc;
+    hipEvent_t *tv = st ? nullptr : time_slot(c, 0);
+#define MARK(i) do { if (tv) DOTS_HIP(hipEventRecord(tv[i], c->stream)); } while (0)
+    MARK(0);
     if ((rc = palm_step0(c))) return rc;
     // the right-hand side of this iteration was enqueued behind the KKT kernels of the last one (DOTS_STEP_RHS_AHEAD) and nothing
     // it reads has changed since: start at the solve; the projection then runs with the inverse transform
@@ -324,15 +354,26 @@ static int run_iteration(Ctx *c, dots_step_stats *st) {
         c->zmid_stale = c->step_skip_zmid;
         if (rhs_takes_soc(c) && !ahead) {   // [right-hand side + projection] -> sweeps -> inverse transform -> steps 2+3
             if ((rc = launch_rhs(c, true))) return rc;
+            MARK(1);
             if ((rc = cg_solve(c, nullptr))) return rc;
-            return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
+            MARK(2);
+            MARK(3);
+            if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
+            MARK(4);
+            return 0;
         }
         const bool fuse = soc_takes_inverse(c);
         if (!ahead && (rc = launch_rhs(c))) return rc;
+        MARK(1);
         if ((rc = cg_solve(c, nullptr, fuse))) return rc;
+        MARK(2);
         if ((rc = launch_soc_projection(c, 1, fuse))) return rc;
-        return launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1);
+        MARK(3);
+        if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
+        MARK(4);
+        return 0;
     }
+#undef MARK
     DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
     if (!ahead && (rc = launch_rhs(c))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
@@ -409,15 +450,27 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
     DOTS_HIP(hipSetDevice(desc->device));
     dots_ctx *c = new dots_ctx();
     c->device = desc->device;
-    if (const char *e = getenv("DOTS_CG_STAGE_LDS")) c->cg_stage_lds = atoi(e) != 0;
-    if (const char *e = getenv("DOTS_MG_TAIL_ROWS")) c->mg_tail_rows = atoi(e);
-    if (const char *e = getenv("DOTS_SOC_WITH_RHS")) c->soc_with_rhs = atoi(e) != 0;
-    if (const char *e = getenv("DOTS_QL_TWO")) c->ql_two = atoi(e);
-    if (const char *e = getenv("DOTS_KKT_TWO")) c->kkt_two = atoi(e);
-    if (const char *e = getenv("DOTS_RHS_TWO")) c->rhs_two = atoi(e);
-    if (const char *e = getenv("DOTS_SPIN_FETCH")) c->spin_fetch = atoi(e);
-    if (const char *e = getenv("DOTS_FRONT_VEC2")) c->front_vec2 = atoi(e);      // 0 never, 1 / 2 wherever the pitch allows (default), 3 only where bandwidth-bound
-    if (const char *e = getenv("DOTS_FRONT_RB")) c->front_rb_max = std::min(4, std::max(1, atoi(e)));
+    // measurement switches: every value is validated -- a typo must not silently select the default
+    {
+        bool ok = true;
+        ok &= env_int("DOTS_CG_STAGE_LDS", 0, 1, &c->cg_stage_lds);
+        ok &= env_int("DOTS_MG_TAIL_ROWS", 0, 1 << 20, &c->mg_tail_rows);
+        ok &= env_int("DOTS_SOC_WITH_RHS", 0, 1, &c->soc_with_rhs);
+        ok &= env_int("DOTS_QL_TWO", 0, 1, &c->ql_two);
+        ok &= env_int("DOTS_KKT_TWO", 0, 1, &c->kkt_two);
+        ok &= env_int("DOTS_RHS_TWO", 0, 1, &c->rhs_two);
+        ok &= env_int("DOTS_SPIN_FETCH", 0, 1, &c->spin_fetch);
+        ok &= env_int("DOTS_FRONT_VEC2", 0, 3, &c->front_vec2);      // 0 never, 1 / 2 wherever the pitch allows (default), 3 only where bandwidth-bound
+        ok &= env_int("DOTS_FRONT_RB", 1, 4, &c->front_rb_max);
+        ok &= env_int("DOTS_FRONT_ROWS", 0, 2, &c->front_rows);      // 0: the fold kernels everywhere, 1: row kernels where the rules say (default), 2: wherever they fit
+        ok &= env_int("DOTS_FRONT_XCD", 0, 1, &c->front_xcd);
+        ok &= env_int("DOTS_FRONT_TUNE", 0, 2, &c->front_tune);
+        ok &= env_int("DOTS_MAIL_TEST_DROP", 0, 1 << 20, &c->mail_test_drop);
+        int spins = -1;
+        ok &= env_int("DOTS_MAIL_SPINS", 0, 2000000000, &spins);
+        if (spins >= 0) c->mail_spins = spins;
+        if (!ok) { delete c; return DOTS_ERR_ARGUMENT; }
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);
@@ -442,6 +495,8 @@ int dots_destroy(dots_ctx *c) {
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &slot : c->tev)
+        for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -551,7 +606,10 @@ int dots_slab_stage(dots_ctx *c, int stage, dots_step_stats *stats) {
     if (stage <= 3 && stage != c->slab_stage) { set_error("slab_stage: stages must be called in the order 0, 1, 2, 3"); return DOTS_ERR_STATE; }
     if (stage == 4 && c->slab_stage != 0) { set_error("slab_stage: the KKT halos are packed between iterations"); return DOTS_ERR_STATE; }
     if (!stats) {
+        hipEvent_t *tv = stage <= 3 ? time_slot(c, 1 + stage) : nullptr;
+        if (tv) DOTS_HIP(hipEventRecord(tv[0], c->stream));
         if ((rc = slab_stage(c, stage))) return rc;
+        if (tv) DOTS_HIP(hipEventRecord(tv[1], c->stream));
     } else {
         DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
         if ((rc = slab_stage(c, stage))) return rc;
@@ -599,12 +657,55 @@ int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
 int dots_step_flags(dots_ctx *c, uint32_t flags) {
     int rc = check(c, true);
     if (rc) return rc;
-    if (flags & ~(uint32_t)(DOTS_STEP_SKIP_Z_MID | DOTS_STEP_PALM | DOTS_STEP_RHS_AHEAD)) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
+    if (flags & ~(uint32_t)(DOTS_STEP_SKIP_Z_MID | DOTS_STEP_PALM | DOTS_STEP_RHS_AHEAD | DOTS_STEP_TIMED)) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
     if ((flags & DOTS_STEP_RHS_AHEAD) && (flags & DOTS_STEP_PALM)) { set_error("step_flags: DOTS_STEP_RHS_AHEAD cannot be combined with DOTS_STEP_PALM (its step 0 changes what the right-hand side reads)"); return DOTS_ERR_ARGUMENT; }
     c->rhs_ahead_armed = ((flags & DOTS_STEP_RHS_AHEAD) && rhs_writes_modes(c)) ? 1 : 0;      // (a hint: ignored without the direct solver / on a time slab)
     if ((flags & DOTS_STEP_SKIP_Z_MID) && (flags & DOTS_STEP_PALM)) { set_error("step_flags: DOTS_STEP_PALM reads z_mid, it cannot be combined with DOTS_STEP_SKIP_Z_MID"); return DOTS_ERR_ARGUMENT; }
     c->step_skip_zmid = (flags & DOTS_STEP_SKIP_Z_MID) ? 1 : 0;
     c->step_palm = (flags & DOTS_STEP_PALM) ? 1 : 0;
+    c->step_timed = (flags & DOTS_STEP_TIMED) ? 1 : 0;
+    return 0;
+}
+
+int dots_step_times(dots_ctx *c, dots_step_stats *out, int capacity, int wait, int *n_out) {
+    int rc = check(c, true);
+    if (rc) return rc;
+    if (!out || !n_out || capacity < 0) { set_error("step_times: bad argument"); return DOTS_ERR_ARGUMENT; }
+    int n = 0;
+    while (n < capacity && c->t_count > 0) {
+        hipEvent_t *tv = c->tev[c->t_head];
+        const int kind = c->tkind[c->t_head];
+        hipEvent_t last = tv[kind == 0 ? 4 : 1];
+        if (wait) DOTS_HIP(hipEventSynchronize(last));
+        else {
+            const hipError_t q = hipEventQuery(last);
+            if (q == hipErrorNotReady) break;
+            DOTS_HIP(q);
+        }
+        dots_step_stats &st = out[n];
+        memset(&st, 0, sizeof st);
+        float t;
+        if (kind == 0) {
+            DOTS_HIP(hipEventElapsedTime(&t, tv[0], tv[1])); st.ms_rhs = t;
+            DOTS_HIP(hipEventElapsedTime(&t, tv[1], tv[2])); st.ms_laplacian = t;
+            DOTS_HIP(hipEventElapsedTime(&t, tv[2], tv[3])); st.ms_soc = t;
+            DOTS_HIP(hipEventElapsedTime(&t, tv[3], tv[4])); st.ms_q_lambda_multiplier = t;
+            DOTS_HIP(hipEventElapsedTime(&t, tv[0], tv[4])); st.ms_total = t;
+            st.alm_iterations = 1;
+        } else {
+            const int stage = kind - 1;
+            DOTS_HIP(hipEventElapsedTime(&t, tv[0], tv[1]));
+            st.ms_total = t;
+            if (stage == 0) st.ms_rhs = t;                              // packing the halos
+            if (stage == 1) st.ms_rhs = st.ms_soc = 0.5 * t;            // one launch: right-hand side and projection together
+            if (stage == 2) st.ms_laplacian = t;
+            if (stage == 3) { st.ms_q_lambda_multiplier = t; st.alm_iterations = 1; }
+        }
+        c->t_head = (c->t_head + 1) % Ctx::TIME_SLOTS;
+        c->t_count -= 1;
+        ++n;
+    }
+    *n_out = n;
     return 0;
 }
 
@@ -655,6 +756,17 @@ int dots_kkt_sums(dots_ctx *c, uint32_t mask, double *sums) {
         return DOTS_ERR_STATE;
     }
     return kkt_sums(c, mask, sums);
+}
+int dots_kkt_sums_device(dots_ctx *c, uint32_t mask, double *device_sums) {
+    int rc = check(c, true);
+    if (rc) return rc;
+    if (!device_sums || (mask >> DOTS_N_KKT)) { set_error("kkt_sums_device: bad mask or null output"); return DOTS_ERR_ARGUMENT; }
+    if (c->zmid_stale && (mask & (1u << DOTS_KKT_PRIM_Z))) { set_error("kkt: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
+    if (c->shard_stride != 0 && !c->kkt_halo_fresh && (mask & ((1u << DOTS_KKT_DUAL_ALPHA) | (1u << DOTS_KKT_COMP_RHO_FQ) | (1u << DOTS_KKT_COMP_M_RHO_B)))) {
+        set_error("kkt_sums_device: the KKT halos are stale (dots_slab_stage 4 + exchange first)");
+        return DOTS_ERR_STATE;
+    }
+    return kkt_sums_device(c, mask, device_sums);
 }
 int dots_kkt_combine(dots_ctx *c, uint32_t mask, const double *sums, double *out) {
     int rc = check(c, true);
@@ -876,6 +988,15 @@ int dots_front_info(dots_ctx *c, double *out) {
 int dots_front_pitch(dots_ctx *c) {
     if (check(c)) return -1;
     return c->dcg.TP;
+}
+
+int64_t dots_debug_counter(dots_ctx *c, int which) {
+    if (!c) return -1;
+    switch (which) {
+        case 0: return c->mail_fallbacks;
+        case 1: return (int64_t)c->mail_seq;
+        default: return -1;
+    }
 }
 
 int dots_bench_kernel(dots_ctx *c, int which, int reps, double *ms, double *bytes) {

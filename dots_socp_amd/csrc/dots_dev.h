@@ -219,7 +219,9 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x);   // x = A^-1
 int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, int nb, int ept, int vt, int G);  // enqueue z = MG(r); z holds D^-1 r on entry
 int kkt_evaluate(Ctx *c, uint32_t mask, double *out);
 int kkt_sums(Ctx *c, uint32_t mask, double *sums);                          // the weighted sums of this context's time slab
+int kkt_sums_device(Ctx *c, uint32_t mask, double *device_sums);            // the same, left in the caller's device buffer (enqueue only)
 int kkt_combine(Ctx *c, uint32_t mask, const double *sums, double *out);    // the residuals from the sums of the whole problem
+bool env_int(const char *name, int lo, int hi, int *out);                   // validated integer switch from the environment
 int kkt_n_sums();
 int objective_evaluate(Ctx *c, double *out);
 int objective_sums(Ctx *c, double *sums);
@@ -257,6 +259,12 @@ struct Ctx {
     uint64_t mail_seq = 0;
     int *kkt_counter = nullptr;   // device counter of k_reduce_mail (last workgroup publishes)
     int spin_fetch = 1;           // DOTS_SPIN_FETCH=0: copy + stream synchronise instead of the device-written mailbox (A/B measurements)
+    int64_t mail_spins = 20000000;   // host spins on the mailbox before it blocks on the stream (DOTS_MAIL_SPINS)
+    int64_t mail_fallbacks = 0;   // evaluations whose sequence number never arrived: sums copied from the device scalars instead
+    int mail_test_drop = 0;       // DOTS_MAIL_TEST_DROP=n (tests): every n-th evaluation publishes a wrong sequence number
+    int front_rows = 1;           // row-per-lane-group sweep kernels on bands of short rows (DOTS_FRONT_ROWS: 0 never, 1 by rule, 2 wherever they fit)
+    int front_xcd = 1;            // DOTS_FRONT_XCD=0: plain work-list order in the sweeps
+    int front_tune = 0;           // DOTS_FRONT_TUNE=1 print the per-band timing table, 2 also apply the fastest choice
     int *h_flags = nullptr;
     int n_partial_blocks = 0;
     int last_cg_iters = 0;
@@ -269,6 +277,12 @@ struct Ctx {
     int kkt_two = 1;              // KKT sums with two nodes per lane (one GPU; DOTS_KKT_TWO=0: one)
     int ql_two = 1;               // steps 2+3 with two nodes per lane (DOTS_QL_TWO=0: one, for A/B measurements)
     int rhs_two = 1;              // right-hand side + projection with two time columns per lane (DOTS_RHS_TWO=0: one)
+    // DOTS_STEP_TIMED: phase events of enqueue-only steps, collected later by dots_step_times (no host wait in the loop)
+    static constexpr int TIME_SLOTS = 64;
+    hipEvent_t tev[TIME_SLOTS][5]{};  // created on first use
+    int tkind[TIME_SLOTS]{};      // 0: a whole dots_step iteration (5 events), 1 + stage: one dots_slab_stage (events 0 and 1)
+    int t_head = 0, t_count = 0;  // ring: oldest slot, slots in flight
+    int step_timed = 0;           // dots_step_flags
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
     int step_palm = 0;            // dots_step_flags: every iteration opens with the (q, lambda_c) closed form (is_palm = True)
     int zmid_stale = 0;           // z_mid does not belong to the current iterate

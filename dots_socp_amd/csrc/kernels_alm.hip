@@ -755,6 +755,9 @@ static int grid_for(int64_t n) {
 int launch_scale_array(Ctx *c, int id, double f) {
     const int64_t n = array_count_device(c->d, id);
     hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(BLOCK), 0, c->stream, c->arr(id), n, f);
+    // a time slab keeps phi at the next slab's first node beside its own columns (written by the inverse transform, read by
+    // grad_time in the KKT and norm kernels until the next solve): it is scaled with phi
+    if (id == DOTS_PHI && c->d.slab && c->d.phi_hi) hipLaunchKernelGGL(k_scale, dim3(grid_for(c->d.V)), dim3(BLOCK), 0, c->stream, c->d.phi_hi, (int64_t)c->d.V, f);
     DOTS_HIP(hipGetLastError());
     return 0;
 }

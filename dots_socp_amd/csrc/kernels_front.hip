@@ -1068,7 +1068,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     // knot 49.3 -> 44.0, sphere10k 97.4 -> 89.5, knot63 80.0 -> 74.0; launches of few large nodes (>= 100 workgroups per node:
     // the top of torus100k) lose 4 % with it and keep the plain order; the large launches below them do not care.
     // DOTS_FRONT_XCD=0: plain order everywhere.
-    const bool xcd_deal = !(getenv("DOTS_FRONT_XCD") && atoi(getenv("DOTS_FRONT_XCD")) == 0);
+    const bool xcd_deal = c->front_xcd != 0;
     auto deal = [&](std::vector<FrontWork> &list, size_t from, size_t n_nodes) {
         const size_t n = list.size() - from;
         if (!xcd_deal || n_nodes < 8 || n < 16 || n > 80 * n_nodes) return;
@@ -1080,7 +1080,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
                 if (x * per + s2 < n) out.push_back(list[from + x * per + s2]);
         std::copy(out.begin(), out.end(), list.begin() + (std::ptrdiff_t)from);
     };
-    if (getenv("DOTS_FRONT_TUNE")) {     // time every (threads, rows) choice per band and sweep on this device; prints the table
+    if (c->front_tune) {     // DOTS_FRONT_TUNE: time every (threads, rows) choice per band and sweep on this device; prints the table
         std::vector<void *> tmp;
         double *vec[3] = {nullptr, nullptr, nullptr};
         bool ok = true;
@@ -1091,7 +1091,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         ok = ok && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-        const int apply = atoi(getenv("DOTS_FRONT_TUNE"));
+        const int apply = c->front_tune;
         for (int k = 0; k < nb && ok; ++k)
             for (int sweep = 0; sweep < 2 && ok; ++sweep) {
                 if (sweep == 1 && top_inv && k == nb - 1) continue;      // no backward launch there

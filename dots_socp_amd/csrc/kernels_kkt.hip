@@ -483,6 +483,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_mail(const double *__restrict_
     block_sum<1>(v, lds);
     if (threadIdx.x == 0) {
         out[slot] = v[0];
+        if (!mail) return;               // device hand-over (dots_kkt_sums_device): the caller's stream order publishes `out`
         mail[slot] = v[0];
         __threadfence_system();
         if (atomicAdd(counter, 1) == (int)gridDim.x - 1) {
@@ -496,11 +497,24 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_mail(const double *__restrict_
 static int wait_mail(Ctx *c, double seq, int n) {
     volatile double *flag = c->h_mail + MAX_SUMS;
     bool got = false;
-    for (int64_t spins = 0; spins < 20000000; ++spins) {        // ~ tens of ms at most; then the blocking wait
+    for (int64_t spins = 0; spins < c->mail_spins; ++spins) {   // ~ tens of ms at most; then the blocking wait
         if (*flag == seq) { got = true; break; }
         __builtin_ia32_pause();
     }
-    if (!got) DOTS_HIP(hipStreamSynchronize(c->stream));
+    if (!got) {
+        // The spin ran out (DOTS_MAIL_SPINS, default ~ tens of ms): block until the stream has drained.  If the sequence number
+        // still has not arrived the publish did not happen (e.g. the counter of k_reduce_mail was left non-zero by an
+        // interrupted launch): never hand stale sums to the stop / penalty decisions -- reset the counter and copy the sums
+        // from the device scalars, where k_reduce_mail / k_mail_sums' source also hold them.
+        DOTS_HIP(hipStreamSynchronize(c->stream));
+        if (*flag != seq) {
+            c->mail_fallbacks += 1;
+            if (c->kkt_counter) DOTS_HIP(hipMemsetAsync(c->kkt_counter, 0, 2 * sizeof(int), c->stream));
+            DOTS_HIP(hipMemcpyAsync(c->h_pinned, c->d.scal + S::SUMS, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+            DOTS_HIP(hipStreamSynchronize(c->stream));
+            return 0;
+        }
+    }
     std::atomic_thread_fence(std::memory_order_acquire);
     for (int i = 0; i < n; ++i) c->h_pinned[i] = c->h_mail[i];
     return 0;
@@ -509,12 +523,36 @@ static int wait_mail(Ctx *c, double seq, int n) {
 static int fetch_sums(Ctx *c, int n) {
     if (c->spin_fetch && c->h_mail && n <= MAX_SUMS && n <= 64) {
         const double seq = (double)(++c->mail_seq);
-        hipLaunchKernelGGL(k_mail_sums, dim3(1), dim3(64), 0, c->stream, c->d.scal + S::SUMS, n, c->h_mail, seq);
+        const bool drop = c->mail_test_drop > 0 && c->mail_seq % (uint64_t)c->mail_test_drop == 0;      // tests: this publish goes astray
+        hipLaunchKernelGGL(k_mail_sums, dim3(1), dim3(64), 0, c->stream, c->d.scal + S::SUMS, n, c->h_mail, drop ? -seq : seq);
         DOTS_HIP(hipGetLastError());
         return wait_mail(c, seq, n);
     }
     DOTS_HIP(hipMemcpyAsync(c->h_pinned, c->d.scal + S::SUMS, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     DOTS_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// The sums left in the caller's DEVICE buffer (a time slab hands them straight to the all-reduce): enqueue only, no host wait.
+int kkt_sums_device(Ctx *c, uint32_t mask, double *out) {
+    const Dev &d = c->d;
+    const dots_params &p = c->prm;
+    KktArgs a{mask, p.r, p.scale_z, p.const_d, p.congestion, p.prim_scale, p.dual_scale, p.boundary_scale};
+    const bool two = c->kkt_two && !d.slab && d.TP >= 4;
+    const int per_tile = two ? TILE_ELEMS / (2 * BLOCK) : TILE_ELEMS / BLOCK;
+    const int gv = xcd_grid(d.n_vtiles) * per_tile, gf = xcd_grid(d.n_ftiles) * per_tile;
+    double *part_f = d.partials + (int64_t)N_VSUMS * gv;
+    const bool need_v = mask & (1u | 2u | 4u | 8u | 16u | 64u), need_f = mask & (1u | 2u | 8u | 32u);
+    const int nv = (need_v && d.nl > 0) ? gv : 0, nf = (need_f && d.nl > 0) ? gf : 0;
+    if (nv + nf == 0) {      // nothing to sum (no mask bit, or a rank without nodes): zeros
+        DOTS_HIP(hipMemsetAsync(out, 0, sizeof(double) * N_SUMS, c->stream));
+        return 0;
+    }
+    if (two) hipLaunchKernelGGL(k_kkt_sums<true>, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
+    else hipLaunchKernelGGL(k_kkt_sums<false>, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
+    // (a part that did not run sums zero blocks: its slots are zero)
+    hipLaunchKernelGGL(k_reduce_mail, dim3(N_SUMS), dim3(BLOCK), 0, c->stream, d.partials, nv, part_f, nf, out, (double *)nullptr, 0.0, (int *)nullptr);
+    DOTS_HIP(hipGetLastError());
     return 0;
 }
 
@@ -537,7 +575,8 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
     int rc;
     if (c->spin_fetch && c->h_mail && c->kkt_counter) {
         const double seq = (double)(++c->mail_seq);
-        hipLaunchKernelGGL(k_reduce_mail, dim3(N_SUMS), dim3(BLOCK), 0, c->stream, d.partials, nv, part_f, nf, c->d.scal + S::SUMS, c->h_mail, seq, c->kkt_counter);
+        const bool drop = c->mail_test_drop > 0 && c->mail_seq % (uint64_t)c->mail_test_drop == 0;      // tests: this publish goes astray
+        hipLaunchKernelGGL(k_reduce_mail, dim3(N_SUMS), dim3(BLOCK), 0, c->stream, d.partials, nv, part_f, nf, c->d.scal + S::SUMS, c->h_mail, drop ? -seq : seq, c->kkt_counter);
         DOTS_HIP(hipGetLastError());
         // DOTS_STEP_RHS_AHEAD: while the host waits for these sums and decides, the device starts on the next iteration's
         // right-hand side (it reads only what the next dots_step would read; dots_api.hip: check() drops it if anything changes)
@@ -723,13 +762,15 @@ __global__ __launch_bounds__(BLOCK) void k_norm(Dev d, const double *x, int kind
 
 int norm_square(Ctx *c, int id, int part, double *out) {
     const Dev &d = c->d;
-    if (d.slab) { set_error("norm_square works on whole arrays: not available on a time slab"); return DOTS_ERR_STATE; }
+    // (on a time slab: the slab's SHARE of the norm -- its own nodes / intervals / corner entries over the global average
+    //  count; the caller adds the shares of all slabs.  part 1 reads phi_hi, the next slab's first node of the last solve)
     const int kind = array_kind(id);
     if (part != 0 && id != DOTS_PHI) {
         set_error("part != 0 is only defined for DOTS_PHI");
         return DOTS_ERR_ARGUMENT;
     }
     const int g = 512;
+    if (d.nl == 0) { *out = 0.0; return 0; }
     hipLaunchKernelGGL(k_norm, dim3(g), dim3(BLOCK), 0, c->stream, d, c->arr(id), kind, part);
     int rc = reduce_partials(c, d.partials, 1, g, 0);
     if (rc) return rc;

@@ -20,6 +20,20 @@ def _ptr(a, ctype):
     return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
 
 
+def place_slab(name, part, full, n0, nl, ni):
+    """Write the part of the slab that holds the nodes ``[n0, n0 + nl)`` (``ni`` intervals) into a whole array in the reference
+    layout; ``part`` may be longer than the slab along its first axis (padding is ignored).  Corner arrays are indexed by the
+    node an entry is compared with (include/dots_socp_hip.h)."""
+    if name in ("z_mid", "beta_mid"):
+        full[n0:n0 + ni, 0] = part[:ni, 0]
+        lo = 1 if n0 == 0 else 0                           # entry [j][1] is the reference's [n0 + j - 1][1]
+        full[n0 + lo - 1:n0 + nl - 1, 1] = part[lo:nl, 1]
+    else:
+        n = nl if name in ("phi", "B", "E") else ni
+        full[n0:n0 + n] = part[:n]
+    return full
+
+
 class DeviceProblem:
     def __init__(self, n_time, geometry, lap_solver="spacetime_pcg", device=0, reorder=True, plan: DevicePlan | None = None,
                  time_slab=None, nd_leaf=16):
@@ -121,14 +135,7 @@ class DeviceProblem:
 
     def from_slab(self, name, part, full):
         """Write this slab's part into a whole array in the reference layout (entries of other slabs untouched)."""
-        n0, nl, ni = self.node0, self.nl, self.ni
-        if name in ("z_mid", "beta_mid"):
-            full[n0:n0 + ni, 0] = part[:ni, 0]
-            lo = 1 if n0 == 0 else 0
-            full[n0 + lo - 1:n0 + nl - 1, 1] = part[lo:nl, 1]
-        else:
-            full[n0:n0 + part.shape[0]] = part
-        return full
+        return place_slab(name, part, full, self.node0, self.nl, self.ni)
 
     # ---- parameters
     def set_params(self, **kw):
@@ -163,11 +170,20 @@ class DeviceProblem:
         _lib.check(self.lib.dots_step(self._h, int(n_iters), C.byref(st)), "dots_step")
         return st
 
-    def step_flags(self, skip_z_mid=False, palm=False, rhs_ahead=False):
+    def step_flags(self, skip_z_mid=False, palm=False, rhs_ahead=False, timed=False):
         """``rhs_ahead`` (DOTS_STEP_RHS_AHEAD): the first KKT read-back after the next step also enqueues the right-hand side of
-        the iteration after it; only meaningful with the direct solver on one GPU."""
-        flags = (_lib.STEP_SKIP_Z_MID if skip_z_mid else 0) | (_lib.STEP_PALM if palm else 0) | (_lib.STEP_RHS_AHEAD if rhs_ahead else 0)
+        the iteration after it; only meaningful with the direct solver on one GPU.  ``timed`` (DOTS_STEP_TIMED): enqueue-only
+        steps record phase events that ``step_times`` collects later."""
+        flags = ((_lib.STEP_SKIP_Z_MID if skip_z_mid else 0) | (_lib.STEP_PALM if palm else 0) | (_lib.STEP_RHS_AHEAD if rhs_ahead else 0)
+                 | (_lib.STEP_TIMED if timed else 0))
         _lib.check(self.lib.dots_step_flags(self._h, flags), "dots_step_flags")
+
+    def step_times(self, wait=False, capacity=64):
+        """Phase times of the timed enqueue-only steps that have finished (``wait``: of all of them), oldest first."""
+        buf = (_lib.StepStats * capacity)()
+        n = C.c_int(0)
+        _lib.check(self.lib.dots_step_times(self._h, buf, capacity, 1 if wait else 0, C.byref(n)), "dots_step_times")
+        return [buf[i] for i in range(n.value)]
 
     # ---- time slab (multi-GPU): stages of one iteration around the caller's exchanges (dots_slab_stage)
     def slab_elems(self, which):
@@ -219,6 +235,14 @@ class DeviceProblem:
         sums = np.zeros(_lib.KKT_N_SUMS)
         _lib.check(self.lib.dots_kkt_sums(self._h, self._mask(conditions), _ptr(sums, C.c_double)), "dots_kkt_sums")
         return sums
+
+    def kkt_sums_device(self, conditions, device_ptr):
+        """``kkt_sums`` left in the caller's DEVICE buffer of ``KKT_N_SUMS`` doubles (an integer address, e.g. a torch
+        tensor's ``data_ptr()``): only enqueued on the context's stream -- order the consumer with ``stream_wait``."""
+        _lib.check(self.lib.dots_kkt_sums_device(self._h, self._mask(conditions), C.c_void_p(int(device_ptr))), "dots_kkt_sums_device")
+
+    def debug_counter(self, which=0):
+        return int(self.lib.dots_debug_counter(self._h, int(which)))
 
     def kkt_combine(self, conditions, sums):
         """The listed KKT residuals from the sums of the whole problem; same return value as ``kkt``."""

@@ -37,7 +37,8 @@ import time
 
 import numpy as np
 
-from .device import STATE_NAMES
+from ._lib import KKT_N_SUMS
+from .device import STATE_NAMES, place_slab
 from .socp.solver_socp import AlmSolver, DEFAULT_CG_TOL
 
 
@@ -54,10 +55,17 @@ def slab_partition(n_nodes: int, n_ranks: int):
 mode_partition = slab_partition      # the time modes are divided the same way
 
 
-class TorchComm:
-    """Exchanges over torch.distributed (backend "nccl" is RCCL on ROCm)."""
+def _nbytes(t):
+    return int(t.numel()) * int(t.element_size())
 
-    def __init__(self, group=None):
+
+class TorchComm:
+    """Exchanges over torch.distributed (backend "nccl" is RCCL on ROCm).  ``device``: where the small payloads this class
+    builds itself (flags, sums handed over as numpy arrays) live with the nccl backend -- the solver's own device
+    (``ShardedAlmSolver`` sets it; default: torch's current device at the time of the call).  ``calls`` / ``bytes`` count the
+    collectives and what this rank hands to them (send side; an all-gather counts its own chunk)."""
+
+    def __init__(self, group=None, device=None):
         import torch.distributed as dist
 
         self.dist = dist
@@ -65,27 +73,37 @@ class TorchComm:
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
-        self.calls = {"all_gather": 0, "exchange": 0, "all_reduce": 0, "flag": 0}
+        self.device = device
+        self.calls = {"all_gather": 0, "exchange": 0, "all_reduce": 0, "flag": 0, "gather_array": 0}
+        self.bytes = {"all_gather": 0, "exchange": 0, "all_reduce": 0, "flag": 0, "gather_array": 0}
 
     def _peer(self, r):
         return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
+    def _payload_device(self):
+        import torch
+
+        if self.backend != "nccl":
+            return torch.device("cpu")
+        return torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
 
     def all_gather(self, recv, send, sync=True):
         """``sync=False`` (device buffers): the result is only ordered on the current torch stream."""
         import torch
 
         self.calls["all_gather"] += 1
+        self.bytes["all_gather"] += _nbytes(send)
         if self.backend == "nccl":
             self.dist.all_gather_into_tensor(recv, send, group=self.group)
             if sync:
-                torch.cuda.current_stream().synchronize()
+                torch.cuda.current_stream(recv.device).synchronize()
         else:   # gloo: stage through the host
             h_send = send.detach().cpu()
             h_recv = torch.empty(recv.numel(), dtype=recv.dtype)
             self.dist.all_gather_into_tensor(h_recv, h_send, group=self.group)
             recv.copy_(h_recv.to(recv.device))
             if recv.is_cuda and sync:
-                torch.cuda.current_stream().synchronize()
+                torch.cuda.current_stream(recv.device).synchronize()
 
     def exchange(self, n_active, fwd=None, bwd=None, sync=True):
         """Nearest-neighbour exchange among the ranks ``[0, n_active)``.  ``fwd = (send, recv)``: ``send`` goes to rank + 1,
@@ -99,6 +117,8 @@ class TorchComm:
         ops, staged = [], []
 
         def tensor_for(t, receiving):
+            if not receiving:
+                self.bytes["exchange"] += _nbytes(t)
             if self.backend == "nccl":
                 return t
             h = torch.empty(t.numel(), dtype=t.dtype) if receiving else t.detach().cpu()
@@ -123,23 +143,43 @@ class TorchComm:
         for dst, h in staged:
             dst.copy_(h.to(dst.device))
         if self.backend == "nccl" and sync:
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream((fwd or bwd)[0].device).synchronize()
 
-    def all_reduce_sum(self, values: np.ndarray) -> np.ndarray:
+    def all_reduce_sum(self, values) -> np.ndarray:
+        """Sum over the ranks of a small vector; the result as a numpy array on every rank.  ``values``: a numpy array, or a
+        torch tensor -- with the nccl backend a DEVICE tensor is reduced where it lies (the KKT sums go from the kernel that
+        formed them straight to RCCL: no host round trip before the collective; the tensor holds the total afterwards)."""
         import torch
 
         self.calls["all_reduce"] += 1
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.as_tensor(np.ascontiguousarray(values, dtype=np.float64)).to(dev)
+        if isinstance(values, torch.Tensor):
+            t = values if (self.backend == "nccl") == values.is_cuda else values.detach().to(self._payload_device())
+            shape = tuple(values.shape)
+        else:
+            shape = np.shape(values)
+            t = torch.as_tensor(np.ascontiguousarray(values, dtype=np.float64)).to(self._payload_device())
+        self.bytes["all_reduce"] += _nbytes(t)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy().reshape(np.shape(values))
+        return t.cpu().numpy().reshape(shape)
+
+    def all_gather_array(self, part: np.ndarray) -> np.ndarray:
+        """Every rank's ``part`` (same shape and dtype on all ranks), stacked along a new first axis, on every rank."""
+        import torch
+
+        self.calls["gather_array"] += 1
+        part = np.ascontiguousarray(part)
+        send = torch.from_numpy(part).reshape(-1).to(self._payload_device())
+        self.bytes["gather_array"] += _nbytes(send)
+        recv = torch.empty(send.numel() * self.size, dtype=send.dtype, device=send.device)
+        self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        return recv.cpu().numpy().reshape((self.size,) + part.shape)
 
     def any_flag(self, flag: bool) -> bool:
         import torch
 
         self.calls["flag"] += 1
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self._payload_device())
+        self.bytes["flag"] += _nbytes(t)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return bool(t.item())
 
@@ -159,7 +199,9 @@ class ThreadComm:
 
     def __init__(self, shared, rank):
         self.shared, self.rank, self.size, self.backend = shared, rank, shared.n, "thread"
-        self.calls = {"all_gather": 0, "exchange": 0, "all_reduce": 0, "flag": 0}
+        self.device = None
+        self.calls = {"all_gather": 0, "exchange": 0, "all_reduce": 0, "flag": 0, "gather_array": 0}
+        self.bytes = {"all_gather": 0, "exchange": 0, "all_reduce": 0, "flag": 0, "gather_array": 0}
 
     @classmethod
     def group(cls, n):
@@ -170,6 +212,7 @@ class ThreadComm:
         import torch
 
         self.calls["all_gather"] += 1
+        self.bytes["all_gather"] += _nbytes(send)
         s = self.shared
         if send.is_cuda:
             torch.cuda.current_stream().synchronize()     # the payload is complete before another thread's stream reads it
@@ -185,6 +228,8 @@ class ThreadComm:
 
         self.calls["exchange"] += 1
         s, r = self.shared, self.rank
+        if r < n_active:
+            self.bytes["exchange"] += (_nbytes(fwd[0]) if fwd is not None and r + 1 < n_active else 0) + (_nbytes(bwd[0]) if bwd is not None and r > 0 else 0)
         for pair in (fwd, bwd):
             if pair is not None and pair[0].is_cuda:
                 torch.cuda.current_stream().synchronize()
@@ -202,13 +247,26 @@ class ThreadComm:
     def all_reduce_sum(self, values):
         self.calls["all_reduce"] += 1
         s = self.shared
+        if not isinstance(values, np.ndarray) and hasattr(values, "detach"):      # a torch tensor (device or host)
+            values = values.detach().cpu().numpy()
         s.slots[self.rank] = np.array(values, dtype=np.float64)
+        self.bytes["all_reduce"] += s.slots[self.rank].nbytes
         s.barrier.wait()
         total = np.zeros_like(s.slots[0])
         for x in s.slots:          # fixed order: identical on every rank
             total = total + x
         s.barrier.wait()
         return total
+
+    def all_gather_array(self, part):
+        self.calls["gather_array"] += 1
+        s = self.shared
+        s.slots[self.rank] = np.ascontiguousarray(part)
+        self.bytes["gather_array"] += s.slots[self.rank].nbytes
+        s.barrier.wait()
+        out = np.stack(list(s.slots))
+        s.barrier.wait()
+        return out
 
     def any_flag(self, flag):
         self.calls["flag"] += 1
@@ -226,6 +284,8 @@ class ThreadComm:
 class ShardedAlmSolver(AlmSolver):
     """``AlmSolver`` on ``comm.size`` ranks: the state in time slabs, the Laplacian solve over the time modes."""
 
+    EXCHANGE_TAG = "Exchange (halos + two all-gathers)"
+
     def __init__(self, n_time, geometry, comm=None, device=0, buffer_device=None, **kw):
         import torch
 
@@ -236,23 +296,33 @@ class ShardedAlmSolver(AlmSolver):
         kw.setdefault("lap_solver", "modal_direct")
         if kw["lap_solver"] not in ("modal_direct", "modal_pcg"):
             raise ValueError("the sharded solver works on the time modes: lap_solver must be 'modal_direct' or 'modal_pcg'")
-        if kw.get("is_constant_scaling"):
-            raise ValueError("is_constant_scaling needs norms of whole arrays before the first exchange: not available on time slabs")
         self._init_full = kw.pop("init_solution", None) or {}
+        if kw.get("is_constant_scaling") and self._init_full:
+            raise ValueError("a sharded warm start cannot be combined with is_constant_scaling (the initial scaling is applied to the zero state)")
+        tdev = torch.device(buffer_device) if buffer_device is not None else torch.device("cuda", device)
+        # the small payloads the communicator builds itself must live on THIS solver's device (RCCL works on the device of
+        # its tensors: a rank that only passed device=k must not all-reduce on GPU 0)
+        if tdev.type == "cuda":
+            if getattr(comm, "device", None) is None:
+                comm.device = tdev
+            elif torch.device(comm.device) != tdev:
+                raise ValueError(f"the communicator works on {comm.device}, the solver on {tdev}")
         super().__init__(n_time, geometry, device=device, time_slab=(comm.rank, comm.size), **kw)
         dev = self.dev
-        tdev = torch.device(buffer_device) if buffer_device is not None else torch.device("cuda", device)
         nv, nf = dev.slab_elems("vertex_halo"), dev.slab_elems("triangle_halo")
         nb, nx = dev.slab_elems("b_chunk"), dev.slab_elems("x_chunk")
         z = lambda n: torch.zeros(n, dtype=torch.float64, device=tdev)       # noqa: E731
         self.buf = {"send_x": z(nv), "send_nsq": z(nv), "recv_x": z(nv), "recv_nsq": z(nv), "b_send": z(nb), "b_recv": z(nb * comm.size),
                     "x_send": z(nx), "x_recv": z(nx * comm.size), "send_mu": z(nv), "send_b": z(nf), "recv_mu": z(nv), "recv_b": z(nf)}
         dev.slab_set_buffers(**{k: t.data_ptr() for k, t in self.buf.items()})
+        self.kkt_buf = z(KKT_N_SUMS)          # the slab's KKT sums, handed to the all-reduce where the kernels leave them
         self.n_active = dev.active_ranks
         self._on_device = tdev.type == "cuda"
+        self._tdev = tdev
         self._kkt_halo_fresh = False
         self.comm_seconds = 0.0
         self.clock_exchanges = 0
+        self._comm_events = []        # (kind, [(start, end) torch events of the three exchanges]) of timed iterations in flight
         if self._init_full:
             self._upload_initial_slab(self._init_full)
 
@@ -289,51 +359,69 @@ class ShardedAlmSolver(AlmSolver):
         import torch
 
         if self._on_device:
-            self.dev.stream_wait(torch.cuda.current_stream(self.buf["b_send"].device).cuda_stream, ctx_waits=ctx_waits)
+            self.dev.stream_wait(torch.cuda.current_stream(self._tdev).cuda_stream, ctx_waits=ctx_waits)
         elif not ctx_waits:
             self.dev.sync()        # host-staged buffers: the context's work must be complete before the host reads them
 
     def _device_step(self, quiet=False):
+        """With device buffers and the direct solver the four stages and the three exchanges are only ENQUEUED (context stream
+        and communication stream ordered by events, no host wait: read-back iterations wait once, at their KKT sums).  Sampled
+        iterations bracket the stages (DOTS_STEP_TIMED) and the exchanges (events on the communication stream)."""
+        import torch
+
         dev, comm, buf = self.dev, self.comm, self.buf
-        dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm)
-        enqueue_only = quiet and self._on_device and self.direct
-        wait = not enqueue_only
+        kind = "quiet" if quiet else "read-back"
+        sample = self.step_timers.begin(kind)
+        async_ok = self._on_device and self.direct
+        timed = sample and async_ok and len(self._timed_in_flight) <= 56
+        dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, timed=timed)
+        wait = not async_ok
         self._kkt_halo_fresh = False
-        t_comm = 0.0
-        stats = []
-        stats.append(dev.slab_stage(0, wait=wait))
-        t0 = time.perf_counter()
-        self._order(ctx_waits=False)
-        comm.exchange(self.n_active, fwd=(buf["send_x"], buf["recv_x"]), bwd=(buf["send_nsq"], buf["recv_nsq"]), sync=wait)
-        self._order(ctx_waits=True)
-        t_comm += time.perf_counter() - t0
-        stats.append(dev.slab_stage(1, wait=wait))
-        t0 = time.perf_counter()
-        self._order(ctx_waits=False)
-        comm.all_gather(buf["b_recv"], buf["b_send"], sync=wait)
-        self._order(ctx_waits=True)
-        t_comm += time.perf_counter() - t0
-        stats.append(dev.slab_stage(2, wait=wait))
-        t0 = time.perf_counter()
-        self._order(ctx_waits=False)
-        comm.all_gather(buf["x_recv"], buf["x_send"], sync=wait)
-        self._order(ctx_waits=True)
-        t_comm += time.perf_counter() - t0
-        stats.append(dev.slab_stage(3, wait=wait))
         if quiet:
             self.quiet_steps += 1
-        if enqueue_only:
+        if async_ok and not timed:
             self.untimed_steps += 1
-            return
-        st = stats[0]
-        for other in stats[1:]:
-            for name in ("ms_rhs", "ms_laplacian", "ms_soc", "ms_q_lambda_multiplier", "ms_total", "alm_iterations", "cg_iterations"):
-                setattr(st, name, getattr(st, name) + getattr(other, name))
-        st.cg_not_converged = sum(s.cg_not_converged for s in stats)
-        self._account(st)
-        self.comm_seconds += t_comm
-        self.run_history.add_time("Exchange (halos + two all-gathers)", 0.0)
-        self.run_history.steps_time["Exchange (halos + two all-gathers)"] = self.comm_seconds
+        events = []
+
+        def exchange(fn):
+            t0 = time.perf_counter()
+            self._order(ctx_waits=False)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(self._tdev))
+            fn()
+            if timed:
+                e1.record(torch.cuda.current_stream(self._tdev))
+                events.append((e0, e1))
+            self._order(ctx_waits=True)
+            return time.perf_counter() - t0
+
+        t_comm = 0.0
+        stats = [dev.slab_stage(0, wait=wait)]
+        t_comm += exchange(lambda: comm.exchange(self.n_active, fwd=(buf["send_x"], buf["recv_x"]), bwd=(buf["send_nsq"], buf["recv_nsq"]), sync=wait))
+        stats.append(dev.slab_stage(1, wait=wait))
+        t_comm += exchange(lambda: comm.all_gather(buf["b_recv"], buf["b_send"], sync=wait))
+        stats.append(dev.slab_stage(2, wait=wait))
+        t_comm += exchange(lambda: comm.all_gather(buf["x_recv"], buf["x_send"], sync=wait))
+        stats.append(dev.slab_stage(3, wait=wait))
+        if timed:
+            self._timed_in_flight.extend([kind] * 4)
+            self._comm_events.append((kind, events))
+        if wait:        # host-staged exchanges or the PCG: every stage was waited for and timed, the exchanges by the host's clock
+            for st in stats:
+                self._account(st, kind)
+            self.step_timers.add(kind, self.EXCHANGE_TAG, t_comm)
+            self.comm_seconds += t_comm
+
+    def _collect_step_times(self, wait=False):
+        while self._comm_events and (wait or self._comm_events[0][1][-1][1].query()):
+            kind, events = self._comm_events.pop(0)
+            if wait:
+                events[-1][1].synchronize()
+            seconds = 1e-3 * sum(e0.elapsed_time(e1) for e0, e1 in events)
+            self.step_timers.add(kind, self.EXCHANGE_TAG, seconds)
+            self.comm_seconds += seconds
+        super()._collect_step_times(wait=wait)
 
     # ---- scaling tools change mu / B-independent duals in place: the KKT halos of the neighbours are stale afterwards
     def adjust_penalty(self, factor):
@@ -344,6 +432,36 @@ class ShardedAlmSolver(AlmSolver):
         super().scale_variable_z(scale_factor, msg=msg)
         self._kkt_halo_fresh = False
 
+    def scale_prim_dual(self, scale_factor=None):
+        super().scale_prim_dual(scale_factor)
+        self._kkt_halo_fresh = False
+
+    # ---- is_constant_scaling on time slabs (solver_socp.py:324-365): every norm is a sum over space-time -- each rank forms
+    # the share of its slab (dots_norm_square on a slab), ONE small all-reduce adds the shares of all the norms asked for
+    def _norm_squares(self, requests):
+        shares = np.array([self.dev.norm_square(name, part) for name, part in requests])
+        return [float(x) for x in self.comm.all_reduce_sum(shares)]
+
+    def _boundary_gradient_norm(self, bt, phi0):
+        """sqrt(|d_t b|^2 + |d_x b|^2) of the boundary term b (nonzero at the first and the last node only) in the norms of
+        solver_socp.py:215-218: in closed form on the host, from the plan every rank holds (the base class uploads b and asks the
+        device; a slab holds only its own nodes)."""
+        p, T = self.dev.plan, self.n_time
+        h = 1.0 / T
+        mass, area = p.mass_vert, p.area_tri
+        b0, bT = -p.mu0 / (h * mass), p.mu1 / (h * mass)
+        if T == 1:
+            n1 = float(np.sum(((bT - b0) / h) ** 2 * mass)) / T
+        else:
+            n1 = float(np.sum((b0 / h) ** 2 * mass) + np.sum((bT / h) ** 2 * mass)) / T
+        hat, tri = p.hat_grad.reshape(-1, 3, 3), p.triangles.reshape(-1, 3)
+
+        def grad_space_sq(x):
+            g = np.einsum("fkc,fk->fc", hat, x[tri])
+            return float(np.sum(g ** 2 * area[:, None]))
+
+        return float(np.sqrt(n1 + (grad_space_sq(b0) + grad_space_sq(bT)) / (T + 1)))
+
     # ---- read-backs: sums over the slabs
     def _refresh_kkt_halos(self):
         if self._kkt_halo_fresh:
@@ -351,25 +469,38 @@ class ShardedAlmSolver(AlmSolver):
         dev, buf = self.dev, self.buf
         dev.slab_stage(4, wait=False)
         self._order(ctx_waits=False)
-        self.comm.exchange(self.n_active, fwd=(buf["send_mu"], buf["recv_mu"]), bwd=(buf["send_b"], buf["recv_b"]), sync=True)
+        self.comm.exchange(self.n_active, fwd=(buf["send_mu"], buf["recv_mu"]), bwd=(buf["send_b"], buf["recv_b"]), sync=not self._on_device)
         self._order(ctx_waits=True)
         self._kkt_halo_fresh = True
 
     def _kkt(self, conditions):
         self._refresh_kkt_halos()
-        total = self.comm.all_reduce_sum(self.dev.kkt_sums(conditions))
+        if self._on_device:       # kernels -> device buffer -> all-reduce -> ONE copy to the host
+            self.dev.kkt_sums_device(conditions, self.kkt_buf.data_ptr())
+            self._order(ctx_waits=False)
+            total = self.comm.all_reduce_sum(self.kkt_buf)
+        else:
+            total = self.comm.all_reduce_sum(self.dev.kkt_sums(conditions))
         return self.dev.kkt_combine(conditions, total)
 
     def _objective(self):
         return self.dev.objective_combine(self.comm.all_reduce_sum(self.dev.objective_sums()))
 
     def _download(self, name):
-        """The whole array: every rank contributes its slab (the entries of a whole array belong to exactly one rank)."""
+        """The whole array on every rank: an all-gather of the slabs (each entry of a whole array belongs to exactly one rank;
+        a rank hands over its own 1 / R of the array, padded to the common slab length)."""
         dev = self.dev
-        full = np.zeros(dev.full_shape(name))
+        stride, parts = slab_partition(self.n_time + 1, self.comm.size)
+        part = np.zeros((stride,) + tuple(dev.full_shape(name)[1:]))
         if dev.nl > 0:
-            dev.from_slab(name, dev.download(name), full)
-        return self.comm.all_reduce_sum(full)
+            own = dev.download(name)
+            part[:own.shape[0]] = own
+        gathered = self.comm.all_gather_array(part)
+        full = np.zeros(dev.full_shape(name))
+        for begin, count in parts:
+            if count > 0:
+                place_slab(name, gathered[begin // stride], full, begin, count, max(0, min(count, self.n_time - begin)))
+        return full
 
     def _time_is_up(self, reads_back=True):
         """Every rank must leave the loop on the same iteration, so the clock decision is shared (one flag

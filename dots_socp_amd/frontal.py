@@ -265,13 +265,20 @@ def plan_bands(diss: Dissection, node_n, node_b, pitch, max_heights=4, spec=None
     of a sharded run cuts alike."""
     import os
 
+    from ._lib import env_choice
+
     H = int(diss.height.max()) + 1
     spec = os.environ.get("DOTS_FRONT_BANDS", "auto") if spec is None else spec
-    top_spec = os.environ.get("DOTS_FRONT_TOPINV", "auto") if top_spec is None else str(top_spec)
+    top_spec = env_choice("DOTS_FRONT_TOPINV", ("auto", "0", "1"), "auto") if top_spec is None else str(top_spec)
+    if top_spec not in ("auto", "0", "1"):
+        raise ValueError(f"top_inverse must be 'auto', '0' or '1', not {top_spec!r}")
     if spec == "off":
         return np.arange(H + 1, dtype=np.int32), top_spec == "1"
     if spec != "auto":
-        cuts = np.asarray([int(x) for x in str(spec).split(",")], dtype=np.int32)
+        try:
+            cuts = np.asarray([int(x) for x in str(spec).split(",")], dtype=np.int32)
+        except ValueError:
+            raise ValueError(f"band cuts must be 'auto', 'off' or a comma-separated list of tree heights, not {spec!r}") from None
         if cuts[0] != 0 or cuts[-1] != H or np.any(np.diff(cuts) < 1) or np.any(np.diff(cuts) > max_heights):
             raise ValueError(f"bad band cuts {spec!r} for a tree of {H} heights")
         return cuts, top_spec == "1"

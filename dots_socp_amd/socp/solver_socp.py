@@ -25,8 +25,9 @@ import time
 
 import numpy as np
 
-from ..control import (AdaptiveValidator, AdjustAdmmParam, ConditionValidator, ErrorCondition, RunningHistory,
+from ..control import (AdaptiveValidator, AdjustAdmmParam, ConditionValidator, ErrorCondition, RunningHistory, SampledStepTimers,
                        KKT_LABELS, KKT_SHORT_LABELS, max_of_list_with_none, safe_rescale_ratio)
+from .._lib import env_choice
 from ..device import DeviceProblem, STATE_NAMES
 
 logger = logging.getLogger("dots_socp_amd")
@@ -74,14 +75,14 @@ class AlmSolver:
         self.check_kkt_step_by_step = check_kkt_step_by_step
         self.is_palm = bool(is_palm)      # an extra (q, lambda_c) solve opens every iteration (solver_socp.py:668-672)
         self.direct = direct = lap_solver == "modal_direct"
-        self.untimed_steps = 0          # iterations whose phases were not timed (run_history.steps_time holds the others)
+        self.untimed_steps = 0          # iterations whose phases were not timed (run_history.steps_time is estimated from the others)
         self.quiet_steps = 0            # iterations after which nothing was read back
-        self._read_back_steps = 0
+        self._timed_in_flight = []      # kinds of the timed iterations whose events have not been collected yet (one entry per slot)
         # the right-hand side of the iteration after a read-back may be enqueued ahead (iterate(); DOTS_RHS_AHEAD=0 never, =2 always).
         # Only on small problems: the iteration that follows runs its projection apart from its right-hand side, which costs more
         # than the idle time it fills once the kernels are bandwidth-bound, and one launch more from T + 1 = 64 on (measured on the
         # driver's 20 steps: plane20 +2.5 %, knot +1.5 %, sphere10k +0.3 %, knot63 -0.7 %, torus100k -2.5 %)
-        ahead = os.environ.get("DOTS_RHS_AHEAD", "1")
+        ahead = env_choice("DOTS_RHS_AHEAD", ("0", "1", "2"), "1")
         self._rhs_ahead_ok = (direct and time_slab is None and not self.is_palm and not check_kkt_step_by_step
                               and not is_constant_scaling and ahead != "0"
                               and (ahead == "2" or (int(n_time) + 1 < 64
@@ -114,6 +115,8 @@ class AlmSolver:
 
         self.run_history = RunningHistory(max_record_numbers=self.nit, kkt_labels=KKT_LABELS,
                                           kkt_short_labels=KKT_SHORT_LABELS, name="SOCP")
+        # per-step timers without a host wait in the loop (control.SampledStepTimers); DOTS_TIME_EVERY=1 times every iteration
+        self.step_timers = SampledStepTimers(self.run_history, first=4, every=int(env_choice("DOTS_TIME_EVERY", None, "8", integer=(1, 1 << 20))))
         self.adjust_params = AdjustAdmmParam()
         self.is_org_kkt = False
         self.cg_total = self.cg_fail = 0
@@ -185,15 +188,17 @@ class AlmSolver:
         self._kkt_cache = {}
         dev = self.dev
         if scale_factor is None:
-            n2 = dev.norm_square
+            names = [("phi", 1), ("phi", 2), ("A", 0), ("B", 0), ("z_fst", 0), ("z_mid", 0), ("z_end", 0), ("mu", 0), ("E", 0),
+                     ("beta_fst", 0), ("beta_mid", 0), ("beta_end", 0)]
+            n2 = dict(zip(names, self._norm_squares(names)))
             prim = [
-                math.sqrt(n2("phi", 1) + n2("phi", 2)),
-                math.sqrt(n2("A") + n2("B")),
-                math.sqrt(n2("z_fst") + n2("z_mid") + n2("z_end")),
+                math.sqrt(n2["phi", 1] + n2["phi", 2]),
+                math.sqrt(n2["A", 0] + n2["B", 0]),
+                math.sqrt(n2["z_fst", 0] + n2["z_mid", 0] + n2["z_end", 0]),
             ]
             dual = [
-                self.r * math.sqrt(n2("mu") + n2("E")),
-                self.r * math.sqrt(n2("beta_fst") + n2("beta_mid") + n2("beta_end")),
+                self.r * math.sqrt(n2["mu", 0] + n2["E", 0]),
+                self.r * math.sqrt(n2["beta_fst", 0] + n2["beta_mid", 0] + n2["beta_end", 0]),
             ]
             prim_rescale, dual_rescale = AdjustAdmmParam.compute_scale_factor(prim, dual)
         else:
@@ -226,12 +231,21 @@ class AlmSolver:
         bt = np.zeros((n_time + 1, dev.V))        # r * boundary / mass at r = 1
         bt[0], bt[-1] = -mu0 / (h * mass), mu1 / (h * mass)
         norm_c = math.sqrt(float(np.sum(bt ** 2 * mass[None, :])) / (n_time + 1))
-        dev.upload("phi", bt)
-        norm_ac = math.sqrt(dev.norm_square("phi", 1) + dev.norm_square("phi", 2))
-        phi0 = init_solution.get("phi")
-        dev.upload("phi", np.zeros_like(bt) if phi0 is None else np.asarray(phi0, dtype=np.float64))
+        norm_ac = self._boundary_gradient_norm(bt, init_solution.get("phi"))
         self.scale_prim_dual(scale_factor=(self.norm_d, math.sqrt(n_time) * norm_c ** 2 / norm_ac))
         self.adjust_penalty(1.0 / self.r)
+
+    def _boundary_gradient_norm(self, bt, phi0):
+        """sqrt(|d_t b|^2 + |d_x b|^2) of the boundary term (:574-586): the device's own operators on an uploaded copy."""
+        dev = self.dev
+        dev.upload("phi", bt)
+        norm_ac = math.sqrt(dev.norm_square("phi", 1) + dev.norm_square("phi", 2))
+        dev.upload("phi", np.zeros_like(bt) if phi0 is None else np.asarray(phi0, dtype=np.float64))
+        return norm_ac
+
+    def _norm_squares(self, requests):
+        """norm_square_* (:875-878) of the listed (array, part) pairs; the multi-GPU solver adds the slabs' shares."""
+        return [self.dev.norm_square(name, part) for name, part in requests]
 
     def recovered(self, name, arr):
         """recorver_scaled_solution (:397-405)."""
@@ -273,35 +287,47 @@ class AlmSolver:
         ``quiet``: nothing is read back after this iteration (no KKT evaluation, not the last one): z_mid
         need not be stored, and with the direct solver the host does not wait for the device either."""
         # is_palm's step 0 reads z_mid of the previous iteration: it is stored every iteration then
-        self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, rhs_ahead=self._rhs_ahead and not quiet)
         # With the direct solver an iteration needs no host round trip: it is only enqueued, and on iterations that read
         # back the KKT kernels follow it on the stream (one wait, at the read-back).  The phase timers of the history
-        # (Step 1-1 ...: five events and a host wait per iteration) are SAMPLED: the first read-back iterations and every
-        # 16th one after them; the early iterations of a run read back every 1-3 iterations (penalty schedule,
-        # admm_tools.py:43-48) and would otherwise run at host-launch speed.
-        sample = not quiet and (self._read_back_steps < 4 or self._read_back_steps % 16 == 0)
-        if not quiet:
-            self._read_back_steps += 1
-        else:
+        # (Step 1-1 ...) come from SAMPLED iterations whose phases are bracketed by events on the stream, collected at the
+        # next read-back and scaled to all iterations of their kind (control.SampledStepTimers).
+        kind = "quiet" if quiet else "read-back"
+        sample = self.step_timers.begin(kind)
+        if quiet:
             self.quiet_steps += 1
-        if self.direct and not sample:
+        if self.direct:
+            timed = sample and len(self._timed_in_flight) < 60       # (the ring of the library holds 64 slots)
+            self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, rhs_ahead=self._rhs_ahead and not quiet, timed=timed)
             self.dev.step(1, wait=False)
-            self.untimed_steps += 1
-        else:
-            self._account(self.dev.step(1))
+            if timed:
+                self._timed_in_flight.append(kind)
+            else:
+                self.untimed_steps += 1
+        else:       # the PCG waits for its convergence flags anyway: every iteration is timed
+            self._account(self.dev.step(1), kind)
+
+    def _collect_step_times(self, wait=False):
+        """Phase times of the timed iterations that have finished (at a read-back: all of them), into the history."""
+        if self._timed_in_flight:
+            for st in self.dev.step_times(wait=wait):
+                self._account(st, self._timed_in_flight.pop(0))
+        self.step_timers.publish()
 
     def _time_is_up(self, reads_back=True):
         """``reads_back``: this iteration synchronises with the host anyway (the multi-GPU driver only shares the
         clock decision on those iterations)."""
         return (time.perf_counter() - self.start_time) > self.time_limit
 
-    def _account(self, st):
-        hist = self.run_history
+    def _account(self, st, kind):
+        """One dots_step_stats (a whole iteration, or one stage of a time slab: the iteration is complete with the record that
+        carries alm_iterations = 1) of an iteration of ``kind`` into the sampled timers."""
+        tm = self.step_timers
         self.cg_total += st.cg_iterations
         self.cg_fail += st.cg_not_converged
-        hist.add_time("Step 1-1 (Laplacian)", 1e-3 * (st.ms_rhs + st.ms_laplacian))
-        hist.add_time("Step 1-2 (SOC-Projection)", 1e-3 * st.ms_soc)
-        hist.add_time("Step 2+3 (Q & Lambda, Multiplier)", 1e-3 * st.ms_q_lambda_multiplier)
+        done = int(st.alm_iterations)
+        tm.add(kind, "Step 1-1 (Laplacian)", 1e-3 * (st.ms_rhs + st.ms_laplacian), done)
+        tm.add(kind, "Step 1-2 (SOC-Projection)", 1e-3 * st.ms_soc, done)
+        tm.add(kind, "Step 2+3 (Q & Lambda, Multiplier)", 1e-3 * st.ms_q_lambda_multiplier, done)
 
     # ---- one pass of the main loop (:656-823); returns True when the loop must stop ------------
     def iterate(self):
@@ -377,6 +403,8 @@ class AlmSolver:
                 dual_error = max_of_list_with_none([src[i] for i in KKT_DUAL])
                 self.adjust_penalty(params.get_updated_value(self.r, prim_error / dual_error) / self.r)
         hist.record(current_it=it, kkt_errors=org, history=history)
+        if not quiet:
+            self._collect_step_times()      # (the read-back above waited for the stream: every timed iteration so far is complete)
         if not self.check_kkt_step_by_step and error is not None:
             validator.set_error_and_tolerance(error, self.tol)
         return self.finished
@@ -390,6 +418,7 @@ class AlmSolver:
         cost, lagr = self._objective()
         hist.record(current_it=self.counter_main, kkt_errors=org,
                     history={"Transportation cost": cost, "Objective value": lagr})
+        self._collect_step_times(wait=True)
         hist.end()
         hist.solver_stats = {
             "cg_iterations": int(self.cg_total), "cg_not_converged": int(self.cg_fail), "lap_solver": dev.lap_solver,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DOTS_ABI_VERSION 5
+#define DOTS_ABI_VERSION 6
 
 typedef struct dots_ctx dots_ctx;
 
@@ -181,7 +181,16 @@ int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
  * dots_scale_*, dots_run_phase, ...) drops that right-hand side and the step computes it again: results never depend on the
  * flag.  The flag holds for one dots_step. */
 #define DOTS_STEP_RHS_AHEAD 4u
+/* DOTS_STEP_TIMED: enqueue-only steps (dots_step / dots_slab_stage with stats == NULL) bracket their phases with events of an
+ * internal ring of 64 slots (one per dots_step iteration, one per slab stage) WITHOUT waiting for them; dots_step_times collects
+ * the finished slots later, oldest first (the reference's per-step timers, utils/admm_tools.py:244-251, without a host wait in
+ * the loop).  A step that finds the ring full is simply not timed. */
+#define DOTS_STEP_TIMED 8u
 int dots_step_flags(dots_ctx *ctx, uint32_t flags);      /* also apply to dots_slab_stage */
+/* The phase times of the timed steps that have finished (wait != 0: of all timed steps, waiting for them), oldest first, at
+ * most `capacity`: one dots_step_stats per dots_step iteration (alm_iterations = 1), or one per slab stage (the stage's time in
+ * the field of its phase; stage 3 carries alm_iterations = 1). */
+int dots_step_times(dots_ctx *ctx, dots_step_stats *out, int capacity, int wait, int *n_out);
 
 /* ---- time slabs (multi-GPU): one ALM iteration in four stages around three exchanges --------------------------------
  * Every operator of the iteration is local in time except nearest-neighbour couplings (solver_socp.py:884, :892-894,
@@ -246,6 +255,10 @@ int dots_kkt(dots_ctx *ctx, uint32_t mask, double *out /* [2*DOTS_N_KKT] */);
 #define DOTS_KKT_N_SUMS 24
 int dots_kkt_sums(dots_ctx *ctx, uint32_t mask, double *sums /* [DOTS_KKT_N_SUMS] */);
 int dots_kkt_combine(dots_ctx *ctx, uint32_t mask, const double *sums, double *out /* [2*DOTS_N_KKT] */);
+/* dots_kkt_sums with the result left in DEVICE memory of the caller (DOTS_KKT_N_SUMS doubles, e.g. a torch tensor handed to
+ * RCCL's all-reduce): only enqueued on the context's stream, no host wait, no copy -- order the consumer's stream with
+ * dots_stream_wait.  Slots of sums the mask does not need (and every slot on a rank without nodes) are zero. */
+int dots_kkt_sums_device(dots_ctx *ctx, uint32_t mask, double *device_sums /* [DOTS_KKT_N_SUMS], device memory */);
 
 /* objective_functional (solver_socp.py:417-431) as called at :773-775/:829-831:
  * out[0] = transportation cost, out[1] = Lagrangian / objective value. */
@@ -262,7 +275,10 @@ int dots_scale_z(dots_ctx *ctx, double z_mul, double beta_mul, double scale_z_ne
 int dots_scale_arrays(dots_ctx *ctx, uint32_t array_mask, double factor); /* x *= factor for every array in mask (scale_prim_dual :352-358) */
 
 /* weighted squared norms norm_square_* (solver_socp.py:875-878, :215-218) of one state array,
- * and of dt_phi / dx_phi when array_id is DOTS_PHI with part = 1 / 2. */
+ * and of dt_phi / dx_phi when array_id is DOTS_PHI with part = 1 / 2.
+ * On a time slab: the slab's SHARE of the norm (the sum over its own nodes / intervals / corner entries divided by the
+ * GLOBAL averaging count); the caller adds the shares of all slabs (is_constant_scaling, solver_socp.py:324-365).  part = 1
+ * reads phi at the next slab's first node as the last solve (dots_slab_stage 3) left it. */
 int dots_norm_square(dots_ctx *ctx, int array_id, int part, double *out);
 
 /* ---- standalone operators (rows a4-a6 of SURVEY.md section 8a), host in / host out, for tests */
@@ -405,6 +421,10 @@ int dots_front_pitch(dots_ctx *ctx);
  * solve, 4 one calibration launch (k_calib_stream: reads and writes *bytes_per_launch bytes each, 8 B per lane)
  * for the PMC traffic counters */
 int dots_bench_kernel(dots_ctx *ctx, int which, int reps, double *ms_per_launch, double *bytes_per_launch);
+
+/* diagnostics: which = 0 KKT read-backs whose mailbox sequence number never arrived (the sums were then copied from the
+ * device scalars instead: never stale), 1 mailbox hand-overs so far; -1 for an unknown counter */
+int64_t dots_debug_counter(dots_ctx *ctx, int which);
 
 /* device memory in use by the context, bytes */
 int64_t dots_device_bytes(dots_ctx *ctx);

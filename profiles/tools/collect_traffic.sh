@@ -21,6 +21,7 @@ json.dump({"bytes_per_solve": s["front_solve"]["bytes_per_solve"], "read_bytes_p
            "algorithmic_bytes_per_solve": b["roofline"]["algorithmic_bytes_per_solve"],
            "factor_bytes_per_solve_as_installed": b["roofline"]["factor"].get("bytes_per_solve_as_installed"),
            "bands": b["roofline"]["factor"].get("bands"),
+           "kernel_sources_sha256": b["roofline"]["kernel_sources_sha256"],
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) of 'bench.py --workload $w --steps 20 --warmup 5 --no-configs', commit $commit, "
                      "calibrated on k_calib_stream of the same run (profiles/tools/collect_traffic.sh)"},
           open("$out/traffic_${w}.json", "w"), indent=1)

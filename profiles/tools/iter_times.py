@@ -1,5 +1,5 @@
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dots_socp_amd import meshes
 from dots_socp_amd.socp.solver_socp import AlmSolver

@@ -57,7 +57,11 @@ class FakeDeviceProblem:
         self.active_ranks = -(-(n_time + 1) // self.stride)
         self.pitch = max(4, 1 << (self.stride - 1).bit_length())
         self._lu = {}
-        self.plan = types.SimpleNamespace(perm_vert=None, mass_vert=s.mass_v, mu0=self.mu0, mu1=self.mu1)
+        from dots_socp_amd.geometry import build_plan
+
+        real = build_plan(n_time, geometry, reorder=False)       # hat gradients / areas for the closed forms of the driver
+        self.plan = types.SimpleNamespace(perm_vert=None, mass_vert=s.mass_v, mu0=self.mu0, mu1=self.mu1, area_tri=real.area_tri,
+                                          hat_grad=real.hat_grad, triangles=real.triangles)
         self.v2c = O.corner_maps(s.V, s.tri, s.area_f)[2]          # (3F, V) 0/1
         self.stage = 0
         self.kkt_halo_fresh = False
@@ -86,8 +90,11 @@ class FakeDeviceProblem:
         s.bnd[0] = -p.boundary_scale * self.mu0 / (p.r * s.h)
         s.bnd[-1] = p.boundary_scale * self.mu1 / (p.r * s.h)
 
-    def step_flags(self, skip_z_mid=False, palm=False):
+    def step_flags(self, skip_z_mid=False, palm=False, timed=False):
         self.palm = palm
+
+    def step_times(self, wait=False, capacity=64):
+        return []
 
     def setup_frontal(self, **kw):
         return {"levels": 1}
@@ -257,6 +264,34 @@ class FakeDeviceProblem:
     def objective_combine(self, sums):
         assert sums[0] == self.n_ranks
         return self.s.objective()
+
+    # ---- is_constant_scaling: the slab's SHARE of a weighted norm (the driver adds the shares of all ranks)
+    def norm_square(self, name, part=0):
+        s, n0, nl, ni, T = self.s, self.node0, self.nl, self.ni, self.T
+        if nl == 0:
+            return 0.0
+        mass, area = s.mass_v, s.area_f
+        if name == "phi" and part == 1:
+            x = O.grad_time(s.h, s.phi)[n0:n0 + ni]
+            return float(np.sum(x ** 2 * mass[None, :])) / T
+        if name == "phi" and part == 2:
+            x = O.grad_space(s.G, s.F, s.phi)[n0:n0 + nl]
+            return float(np.sum(x ** 2 * area[None, :, None])) / (T + 1)
+        a = getattr(s, name)
+        if name == "phi":
+            return float(np.sum(a[n0:n0 + nl] ** 2 * mass[None, :])) / (T + 1)
+        if name in ("B", "E"):
+            return float(np.sum(a[n0:n0 + nl] ** 2 * area[None, :, None])) / (T + 1)
+        if name in ("z_mid", "beta_mid"):      # an entry belongs to the slab of the NODE it is compared with
+            w = area[None, None, :, None]
+            lo = max(n0 - 1, 0)
+            return (float(np.sum(a[n0:n0 + ni, 0] ** 2 * w)) + float(np.sum(a[lo:n0 + nl - 1, 1] ** 2 * w))) / T
+        return float(np.sum(a[n0:n0 + ni] ** 2 * mass[None, :])) / T
+
+    def scale_arrays(self, names, factor):
+        self.kkt_halo_fresh = False
+        for k in names:
+            setattr(self.s, k, getattr(self.s, k) * factor)
 
     def adjust_penalty(self, factor):
         self.kkt_halo_fresh = False

@@ -48,13 +48,15 @@ def _worker(rank, world, port, fname, out_dir):
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), kkt=hist.kkt_errors, it=hist.kkt_iteration,
                  cost=hist.history["Transportation cost"], mu=sol["mu"], beta_mid=sol["beta_mid"],
                  checked=np.array([alm.dev.checked[k] for k in sorted(alm.dev.checked)]),
-                 calls=np.array([comm.calls[k] for k in sorted(comm.calls)]), iterations=np.array(alm.counter_main + 1))
+                 calls=np.array([comm.calls[k] for k in sorted(comm.calls)]), nbytes=np.array([comm.bytes[k] for k in sorted(comm.bytes)]),
+                 iterations=np.array(alm.counter_main + 1), pitch=np.array(alm.dev.pitch), V=np.array(alm.dev.V), F=np.array(alm.dev.F),
+                 stride=np.array(alm.dev.stride), steps_time=np.array(sum(hist.steps_time.values())))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("fname,world", [("run_refplane4_T8_tol1e-3.npz", 2), ("run_torus_T5_cong_k15_steps.npz", 3),
-                                         ("run_ico1_T6_palm_k12_steps.npz", 2)])
+                                         ("run_ico1_T6_palm_k12_steps.npz", 2), ("run_ico1_T6_cscale_k30_steps.npz", 2)])
 def test_gloo_run_matches_reference(fname, world, tmp_path):
     import torch.multiprocessing as mp
 
@@ -78,12 +80,26 @@ def test_gloo_run_matches_reference(fname, world, tmp_path):
     names = sorted(["recv_x", "recv_nsq", "lamc_lo", "b", "x", "recv_mu", "recv_b"])
     for rank, r in enumerate(ranks):
         checked = dict(zip(names, r["checked"].tolist()))
-        calls = dict(zip(sorted(["all_gather", "exchange", "all_reduce", "flag"]), r["calls"].tolist()))
+        kinds = sorted(["all_gather", "exchange", "all_reduce", "flag", "gather_array"])
+        calls, nbytes = dict(zip(kinds, r["calls"].tolist())), dict(zip(kinds, r["nbytes"].tolist()))
         assert checked["b"] == checked["x"] == n_it and calls["all_gather"] == 2 * n_it
         assert checked["recv_x"] == (n_it if rank > 0 else 0) and checked["lamc_lo"] == (n_it if rank > 0 else 0)
         assert checked["recv_nsq"] == (n_it if rank + 1 < world else 0)
         assert (checked["recv_mu"] > 0) == (rank > 0) and (checked["recv_b"] > 0) == (rank + 1 < world)
         assert calls["all_reduce"] > 0
+        # bytes per collective (what this rank hands over): the two all-gathers carry one slab chunk each; an all-reduce carries
+        # the 24 KKT sums, the 3 objective sums or the 12 norms of is_constant_scaling -- never a state array; the solution
+        # is assembled by all-gathers of the slabs (1 / R of each array per rank, padded to the slab length)
+        V, F, pitch, stride, T = int(r["V"]), int(r["F"]), int(r["pitch"]), int(r["stride"]), int(g["n_time"])
+        assert nbytes["all_gather"] == 8 * n_it * ((V * pitch + V) + V * pitch)
+        assert nbytes["all_reduce"] <= 8 * 24 * calls["all_reduce"] and nbytes["all_reduce"] >= 8 * 3 * calls["all_reduce"]
+        sends = (1 if rank + 1 < world else 0) + (1 if rank > 0 else 0)
+        kkt_exchanges = calls["exchange"] - n_it
+        assert nbytes["exchange"] == 8 * (n_it * sends * V + kkt_exchanges * ((V if rank + 1 < world else 0) + (3 * F if rank > 0 else 0)))
+        full = 8 * ((T + 1) * V + 7 * T * V + 6 * (T + 1) * F + 36 * T * F)
+        assert calls["gather_array"] == 12 and nbytes["gather_array"] == 8 * stride * (8 * V + 6 * F + 36 * F)
+        assert nbytes["gather_array"] < 1.35 * full / world + 8 * (8 * V + 42 * F)
+        assert float(r["steps_time"]) > 0.0
 
 
 def test_slab_partition():

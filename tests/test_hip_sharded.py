@@ -368,5 +368,108 @@ def test_rccl_backend_single_rank(fname, tmp_path):
     assert np.allclose(r["kkt"][m], want[m], rtol=1e-6, atol=1e-13)
     assert np.allclose(r["cost"], g["hist_Transportation_cost"], rtol=1e-6, equal_nan=True)
     assert np.max(np.abs(r["mu"] - g["sol_mu"])) < 1e-5 * np.max(np.abs(g["sol_mu"]))
-    calls = dict(zip(sorted(["all_gather", "exchange", "all_reduce", "flag"]), r["calls"].tolist()))
-    assert calls["all_gather"] > 0 and calls["all_reduce"] > 0
+    calls = dict(zip(sorted(["all_gather", "exchange", "all_reduce", "flag", "gather_array"]), r["calls"].tolist()))
+    assert calls["all_gather"] > 0 and calls["all_reduce"] > 0 and calls["gather_array"] == 12
+
+
+@pytest.mark.parametrize("name,nu,nv,T,n_ranks,nit", [("torus100k", 400, 250, 31, 4, 30), ("torus65k_T127", 360, 180, 127, 8, 30)])
+def test_sharded_parity_at_the_sizes_the_configurations_name(name, nu, nv, T, n_ranks, nit):
+    """BASELINE configs[3] (~100k vertices, T = 31, 4 ranks: slab pitch 8) and configs[4] (V = 64 800, T = 127, 8 ranks: pitch
+    16) sharded at FULL size -- where the 32-bit indices, the chunked-Q tiled transforms and the halo packs see their real
+    extents: 30 iterations with every KKT residual and the objective evaluated each iteration, against the single-context
+    run (KKT / cost 1e-9, mu 1e-8), and for T = 127 against the first 10 iterations the REFERENCE recorded
+    (headline_torus65k_T127.npz, 1e-6); per-rank device memory <= 1.35 x single / R."""
+    from dots_socp_amd import meshes
+    from dots_socp_amd.distributed import ShardedAlmSolver
+    from dots_socp_amd.socp.solver_socp import AlmSolver
+
+    geom, _ = meshes.example("torus", nu=nu, nv=nv)
+    kw = dict(nit=nit, tol=1e-5, check_kkt_step_by_step=True, time_limit=1e9)
+
+    def run(alm):
+        for _ in range(nit):
+            if alm.iterate():
+                break
+        _, hist = alm.finalize(download=False)
+        mu = alm.recovered("mu", alm._download("mu"))
+        out = (hist.kkt_errors.copy(), np.array(hist.history["Transportation cost"]), np.array(hist.history["Objective value"]), mu, alm.dev.device_bytes())
+        alm.close()
+        return out
+
+    kkt1, cost1, obj1, mu1, bytes1 = run(AlmSolver(T, geom, **kw))
+    assert kkt1.shape == (nit, 7) and np.all(np.isfinite(kkt1))
+    results = run_ranks(n_ranks, lambda comm: run(ShardedAlmSolver(T, geom, comm=comm, **kw)))
+    scale = np.max(np.abs(mu1))
+    for kkt, cost, obj, mu, nbytes in results:
+        assert kkt.shape == kkt1.shape
+        assert np.allclose(kkt, kkt1, rtol=1e-9, atol=1e-15)
+        assert np.allclose(cost, cost1, rtol=1e-9) and np.allclose(obj, obj1, rtol=1e-9)
+        assert np.max(np.abs(mu - mu1)) <= 1e-8 * scale
+        assert nbytes <= 1.35 * bytes1 / n_ranks, (nbytes, bytes1)
+    for _, _, _, mu, _ in results[1:]:
+        assert np.array_equal(mu, results[0][3])          # every rank assembles the same solution bit for bit
+    fixture = os.path.join(GOLDEN_DIR, f"headline_{name}.npz")
+    g = np.load(fixture)
+    if "check_kkt_step_by_step" in g.files and bool(g["check_kkt_step_by_step"]):      # the reference's own first iterations
+        n = int(g["nit"])
+        chk = np.array([geom["vertices"].sum(), np.abs(geom["vertices"]).sum(), float(geom["triangles"].sum())])
+        assert np.allclose(chk, g["vertices_checksum"], rtol=1e-13)
+        kkt = results[0][0]
+        assert np.allclose(kkt[:n], g["hist_kkt_errors"], rtol=1e-6, atol=1e-13)
+        assert np.allclose(results[0][1][:n], g["hist_Transportation_cost"], rtol=1e-6)
+
+
+def test_constant_scaling_on_time_slabs():
+    """is_constant_scaling (solver_socp.py:324-365, :574-586) sharded: every norm it needs is a sum over space-time -- the slabs'
+    shares go through one small all-reduce.  Against the reference's recorded run and the single-context solver."""
+    from dots_socp_amd.distributed import solver_socp_sharded
+    from dots_socp_amd.socp import solver_socp
+
+    g = golden("run_ico1_T6_cscale_k30_steps.npz")
+    kw = {k[3:]: (g[k].tolist() if g[k].ndim else g[k].item()) for k in g.files if k.startswith("kw_")}
+    assert kw["is_constant_scaling"]
+    one, one_hist = solver_socp(int(g["n_time"]), geom_of(g), **kw)
+    want = g["hist_kkt_errors"]
+    for n_ranks in (2, 3):
+        results = run_ranks(n_ranks, lambda comm: solver_socp_sharded(int(g["n_time"]), geom_of(g), comm=comm, **kw))
+        for sol, hist in results:
+            assert int(hist.kkt_iteration[-1]) == int(g["last_iteration"])
+            assert np.array_equal(np.isnan(hist.kkt_errors), np.isnan(want))
+            m = ~np.isnan(want)
+            assert np.allclose(hist.kkt_errors[m], want[m], rtol=1e-6, atol=1e-13)
+            assert np.allclose(hist.history["Transportation cost"], g["hist_Transportation_cost"], rtol=1e-6, equal_nan=True)
+            assert np.max(np.abs(sol["mu"] - g["sol_mu"])) < 1e-6 * np.max(np.abs(g["sol_mu"]))
+            for k in ("mu", "E", "A", "B", "beta_mid"):
+                assert np.max(np.abs(sol[k] - one[k])) <= 1e-8 * np.max(np.abs(one[k])), k
+
+
+def test_kkt_sums_reach_the_all_reduce_without_a_host_round_trip():
+    """The 24 KKT sums of a slab stay on the device between the kernels that form them and the all-reduce (dots_kkt_sums_device);
+    the whole arrays are assembled by all-gathers of the slabs.  Counted per collective on two thread-ranks."""
+    from dots_socp_amd import meshes
+    from dots_socp_amd.distributed import ShardedAlmSolver
+
+    geom, _ = meshes.example("sphere", level=2)
+    V, F, T = geom["vertices"].shape[0], geom["triangles"].shape[0], 9
+
+    def rank_main(comm):
+        alm = ShardedAlmSolver(T, geom, comm=comm, nit=40, tol=1e-30)
+        for _ in range(40):
+            alm.iterate()
+        host = alm.dev.kkt_sums(list(range(7)))
+        alm.dev.kkt_sums_device(list(range(7)), alm.kkt_buf.data_ptr())
+        alm.dev.sync()
+        dev_sums = alm.kkt_buf.cpu().numpy().copy()
+        before = dict(comm.bytes)
+        sol, _ = alm.finalize()
+        moved = {k: comm.bytes[k] - before[k] for k in before}
+        stride = alm.dev.slab[2]
+        alm.close()
+        return host, dev_sums, moved, stride, sol["mu"]
+
+    out = run_ranks(2, rank_main)
+    for host, dev_sums, moved, stride, _ in out:
+        assert np.array_equal(host, dev_sums)                                        # same kernels, same sums
+        assert moved["gather_array"] == 8 * stride * (8 * V + 42 * F)                # 12 arrays, 1 / R of each (padded to the slab)
+        assert moved["all_reduce"] == 8 * (24 + 3)                                   # the final KKT sums + the objective's three
+    assert np.array_equal(out[0][4], out[1][4])

@@ -345,3 +345,64 @@ def test_off_reader_round_trip_and_errors(tmp_path):
             meshes.read_off(str(path))
     with pytest.raises(ValueError, match="Error reading .off file"):
         meshes.read_off(str(tmp_path / "missing.off"))
+
+
+def test_environment_switches_are_validated(monkeypatch):
+    """DOTS_* switches are measurement aids: an unknown NAME or a value outside a switch's domain is an error, never a silent
+    default."""
+    from dots_socp_amd import _lib, frontal
+
+    monkeypatch.setenv("DOTS_FRONT_VEC", "0")               # a typo of DOTS_FRONT_VEC2
+    with pytest.raises(_lib.HipLibraryError, match="DOTS_FRONT_VEC"):
+        _lib.check_environment()
+    monkeypatch.delenv("DOTS_FRONT_VEC")
+    _lib.check_environment()
+    monkeypatch.setenv("DOTS_RHS_AHEAD", "yes")
+    with pytest.raises(_lib.HipLibraryError, match="DOTS_RHS_AHEAD"):
+        _lib.env_choice("DOTS_RHS_AHEAD", ("0", "1", "2"), "1")
+    monkeypatch.setenv("DOTS_TIME_EVERY", "0")
+    with pytest.raises(_lib.HipLibraryError, match="DOTS_TIME_EVERY"):
+        _lib.env_choice("DOTS_TIME_EVERY", None, "8", integer=(1, 1 << 20))
+    monkeypatch.setenv("DOTS_TIME_EVERY", "16")
+    assert _lib.env_choice("DOTS_TIME_EVERY", None, "8", integer=(1, 1 << 20)) == "16"
+    # the switches the library reads itself are checked by dots_create / dots_tree_build (host code: no GPU needed for the latter)
+    lib = _lib.load()
+    import ctypes as C
+
+    monkeypatch.setenv("DOTS_ND_PCA_MIN", "many")
+    indptr, indices = np.array([0, 1, 2], dtype=np.int32), np.array([1, 0], dtype=np.int32)
+    xyz = np.zeros((2, 3))
+    h = C.c_void_p()
+    rc = lib.dots_tree_build(2, indptr.ctypes.data_as(C.POINTER(C.c_int32)), indices.ctypes.data_as(C.POINTER(C.c_int32)),
+                             xyz.ctypes.data_as(C.POINTER(C.c_double)), 4, C.byref(h))
+    assert rc != 0 and b"DOTS_ND_PCA_MIN" in lib.dots_last_error()
+    monkeypatch.delenv("DOTS_ND_PCA_MIN")
+    # band cuts / top inverse given as arguments or through the environment
+    monkeypatch.setenv("DOTS_FRONT_TOPINV", "maybe")
+    with pytest.raises(_lib.HipLibraryError, match="DOTS_FRONT_TOPINV"):
+        frontal.plan_bands(None, None, None, 32) if False else _lib.env_choice("DOTS_FRONT_TOPINV", ("auto", "0", "1"), "auto")
+
+
+def test_sampled_step_timers_scale_to_all_iterations():
+    """control.SampledStepTimers: the estimate is (mean of the sampled iterations of a kind) x (iterations of the kind)."""
+    from dots_socp_amd.control import RunningHistory, SampledStepTimers, KKT_LABELS, KKT_SHORT_LABELS
+
+    hist = RunningHistory(max_record_numbers=10, kkt_labels=KKT_LABELS, kkt_short_labels=KKT_SHORT_LABELS, name="t")
+    tm = SampledStepTimers(hist, first=2, every=5)
+    sampled = []
+    for i in range(20):
+        kind = "read-back" if i % 4 == 0 else "quiet"
+        if tm.begin(kind):
+            sampled.append((i, kind))
+            tm.add(kind, "a", 2.0 if kind == "quiet" else 5.0)
+            tm.add(kind, "b", 1.0)
+    tm.publish()
+    assert [i for i, _ in sampled] == [0, 1, 2, 4, 6, 13, 16, 19]        # first two of each kind, then every fifth of its kind
+    assert hist.steps_time["a"] == pytest.approx(15 * 2.0 + 5 * 5.0) and hist.steps_time["b"] == pytest.approx(20.0)
+    assert "20 iterations" in hist.steps_time_note and "8 sampled" in hist.steps_time_note
+    every = SampledStepTimers(hist, first=0, every=1)
+    for _ in range(3):
+        assert every.begin("quiet")
+        every.add("quiet", "a", 1.5)
+    every.publish()
+    assert hist.steps_time["a"] == pytest.approx(4.5) and hist.steps_time_note is None
