@@ -424,7 +424,16 @@ def launch_ranks(args):
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # rank 0 prints the one JSON line; anything else the ranks write to stdout (gloo announces its connections there) goes to stderr
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = proc.stdout.splitlines()
+    result = [ln for ln in lines if ln.startswith('{"metric"')]
+    for ln in lines:
+        if ln not in result and ln.strip():
+            print(ln, file=sys.stderr)
+    if result:
+        print(result[-1])
+    return proc.returncode if result or proc.returncode else 1
 
 
 def main():

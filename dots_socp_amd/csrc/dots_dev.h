@@ -291,6 +291,8 @@ struct Ctx {
     int front_fwd_ptr[66]{}, front_bwd_ptr[66]{};   // workgroup ranges of the tree levels in fwd_desc / bwd_desc
     int front_fwd_rb[65]{}, front_bwd_cb[65]{};     // rows / columns per workgroup on each level
     int front_fwd_nb[65]{}, front_bwd_nb[65]{};     // threads per workgroup on each level (256, or 1024 where a level has few rows)
+    int front_fwd_qw[65]{};       // forward launch of a band: -1 the fold kernel (k_front_fwd), >= 0 the row kernel with 2^qw lane groups per row
+    int front_fwd_lds[65]{};      // row kernel: columns of w a workgroup stages in LDS (the band's longest block)
     int front_planes[65]{};       // update planes the forward launch of a band reads per node (0, 2, 4 or 8)
     int front_vec2 = 1;           // two modes per lane in the sweeps (DOTS_FRONT_VEC2: 0 never, 1 / 2 wherever the pitch allows, 3 only where bandwidth-bound)
     int rhs_ahead_armed = 0;      // DOTS_STEP_RHS_AHEAD: the next KKT launch is followed by the next iteration's right-hand side

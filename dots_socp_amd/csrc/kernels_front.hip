@@ -34,6 +34,7 @@
 #include "dots_dev.h"
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -228,6 +229,117 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
             }
             const int cm = r == q ? cm0 : f.cmap[nd.bdoff + (i - n)];
             vstore<VEC>(f.W + ((nd.parent_w + cm) << sh) + a, s);
+        }
+    }
+}
+
+// ---- forward sweep on bands of SHORT rows: lane groups instead of workgroup folds ----------------------------------------
+// On the lower tree heights a row of F has 5-40 columns.  Split over the 16-64 parts of k_front_fwd most lanes load nothing, and
+// a wavefront executes ~185 vector + ~105 scalar instructions (address arithmetic, the fold through LDS, its barrier) for ONE row:
+// those launches are ISSUE-bound at full occupancy, not memory-bound (SQ counters of the round-2 kernels at torus100k,
+// profiles/r03/r03a_torus100k_sq_counters.txt: 3.5 vector loads per wave, active / wave cycles 0.22-0.24 with 34-49 waves in flight).
+// Here a wavefront is cut into G = 64 / (TP / VEC) lane groups of TP / VEC lanes (one row of modes each); QW = 2^qw_shift
+// consecutive groups share a row of F (QW = 1: a lane walks its row alone), so a wave holds G / QW rows and folds with
+// log2(QW) xor-shuffles; the right-hand side w = b - (planes) of the block's columns is formed ONCE per workgroup, in LDS.
+// A block never spans two members of a merged node (FrontWork.pad = its rows), so wk.lo is the first column of ALL its rows.
+// Sums are formed per part in column order, parts folded pairwise: the order depends on QW only, not on the mode pitch.
+constexpr size_t FWD_ROWS_LDS_MAX = 40 * 1024;      // LDS a workgroup of the row kernel may take for w (4 workgroups per CU stay resident)
+constexpr double FWD_ROWS_MEAN_MAX = 30.0;          // bands whose rows are longer on average keep the fold kernel unless they read 4+ planes (DOTS_FRONT_ROWS=2: no limit)
+constexpr int FWD_ROWS_PAD = 2;      // doubles of padding per staged row of w (rows of exactly TP doubles would share their banks)
+template <bool VMAP, int KP, int VEC>
+__global__ __launch_bounds__(256) void k_front_fwd_rows(FrontArgs g, FrontDev f, const FrontWork *__restrict__ desc, int qw_shift,
+                                                       const double *__restrict__ bhat, double *__restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) double wsh[];      // [columns of the block][TP + FWD_ROWS_PAD]
+    const FrontWork wk = desc[blockIdx.x];
+    const SweepNode &nd = wk.nd;
+    const int sh = g.sh, tid = threadIdx.x;
+    const int shv = VEC == 2 ? sh - 1 : sh;                      // log2 of the lanes per row of modes
+    const int a = (tid & ((1 << shv) - 1)) * VEC;
+    const int grp = tid >> shv;                                  // lane group of the workgroup
+    const int part = grp & ((1 << qw_shift) - 1), QW = 1 << qw_shift;
+    const int r = grp >> qw_shift;                               // row of the block
+    const int n = nd.n, m = n + nd.b;
+    const int row0 = wk.first, nr = wk.pad, lo = wk.lo;
+    const int i = row0 + r;
+    const bool live = a < g.ncol, rowok = r < nr;
+    const int last = row0 + nr - 1;
+    const int jmax = wk.end > 0 ? wk.end : (last < n ? last + 1 : n);
+    const int64_t plane = (int64_t)m << sh;
+    const double *__restrict__ W0 = f.W + (nd.woff << sh) + a;         // plane 0; plane k is k * m rows further
+    const int ldw = g.TP + FWD_ROWS_PAD;
+    if (live) {
+        for (int j = lo + grp; j < jmax; j += 256 >> shv) {
+            const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
+            Vd<VEC> w = vload<VEC>(bhat + (row << sh) + a);
+            if (KP > 0) {
+                Vd<VEC> wp[KP > 0 ? KP : 1];
+#pragma unroll
+                for (int k = 0; k < KP; ++k) wp[k] = vload<VEC>(W0 + k * plane + ((int64_t)j << sh));
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    double t = wp[0].v[c];
+#pragma unroll
+                    for (int k = 1; k < KP; ++k) t += wp[k].v[c];
+                    w.v[c] -= t;
+                }
+            }
+            vstore<VEC>(wsh + (j - lo) * ldw + a, w);
+        }
+    }
+    // where an update row goes in the parent's plane, and what the children carried to it: loaded now, needed after the loop
+    const bool store = part == 0 && rowok && live;
+    const bool upd = store && i >= n;
+    const int cm = upd ? f.cmap[nd.bdoff + (i - n)] : 0;
+    Vd<VEC> cp[KP > 0 ? KP : 1];
+    if (KP > 0 && upd) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) cp[k] = vload<VEC>(W0 + k * plane + ((int64_t)i << sh));
+    }
+    __syncthreads();
+    Vd<VEC> acc;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc.v[c] = 0.0;
+    if (rowok && live) {
+        const int jend = wk.end > 0 ? wk.end : (i < n ? i + 1 : n);
+        const double *__restrict__ Fi = f.F + (nd.foff << sh) + a + (((int64_t)i * n) << sh);
+        const double *ws = wsh + a - lo * ldw;
+        constexpr int U = 4;
+        int j = lo + part;
+        for (; j + (U - 1) * QW < jend; j += U * QW) {
+            Vd<VEC> fv[U], wv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) fv[u] = vload<VEC>(Fi + ((int64_t)(j + u * QW) << sh));
+#pragma unroll
+            for (int u = 0; u < U; ++u) wv[u] = vload<VEC>(ws + (j + u * QW) * ldw);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc.v[c] += fv[u].v[c] * wv[u].v[c];
+        }
+        for (; j < jend; j += QW) {
+            const Vd<VEC> fv = vload<VEC>(Fi + ((int64_t)j << sh)), wv = vload<VEC>(ws + j * ldw);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) acc.v[c] += fv.v[c] * wv.v[c];
+        }
+    }
+    for (int o = 1 << shv; o < (1 << (shv + qw_shift)); o <<= 1) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc.v[c] += __shfl_xor(acc.v[c], o, 64);
+    }
+    if (store) {
+        if (i < n) {
+            vstore<VEC>(Y + (front_row(f, nd.k0 + i) << sh) + a, acc);
+        } else {   // update row: carry the children's contributions on, hand the sum to the parent's plane
+            if (KP > 0) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    double u = cp[0].v[c];
+#pragma unroll
+                    for (int k = 1; k < KP; ++k) u += cp[k].v[c];
+                    acc.v[c] += u;
+                }
+            }
+            vstore<VEC>(f.W + ((nd.parent_w + cm) << sh) + a, acc);
         }
     }
 }
@@ -445,6 +557,29 @@ static void front_launch_fwd(Ctx *c, const FrontDev &f, const FrontWork *ptr, in
     else { if (blk == 1) FRONT_FWD(256, 1); else if (blk == 2) FRONT_FWD(256, 2); else FRONT_FWD(256, 4); }
 #undef FRONT_FWD
 #undef FRONT_FWD4
+}
+
+// one band of the forward sweep with the row kernel: n workgroups of 256 threads, 2^qw_shift lane groups per row
+static void front_launch_fwd_rows(Ctx *c, const FrontDev &f, const FrontWork *ptr, int n, int qw_shift, int kp, int lds_cols, const double *bhat, double *y) {
+    const Dev &d = c->dcg;
+    const FrontArgs g{d.tp_shift, d.TP, d.cg_ncol};
+    const bool vm = f.vmap != nullptr, v2 = front_two_modes(c);
+    const size_t lds = sizeof(double) * (size_t)std::max(lds_cols, 1) * (size_t)(d.TP + FWD_ROWS_PAD);
+#define FRONT_ROWS4(KPV)                                                                                                           \
+    do {                                                                                                                           \
+        if (v2) {                                                                                                                  \
+            if (vm) hipLaunchKernelGGL((k_front_fwd_rows<true, KPV, 2>), dim3(n), dim3(256), lds, c->stream, g, f, ptr, qw_shift, bhat, y);  \
+            else hipLaunchKernelGGL((k_front_fwd_rows<false, KPV, 2>), dim3(n), dim3(256), lds, c->stream, g, f, ptr, qw_shift, bhat, y);    \
+        } else {                                                                                                                   \
+            if (vm) hipLaunchKernelGGL((k_front_fwd_rows<true, KPV, 1>), dim3(n), dim3(256), lds, c->stream, g, f, ptr, qw_shift, bhat, y);  \
+            else hipLaunchKernelGGL((k_front_fwd_rows<false, KPV, 1>), dim3(n), dim3(256), lds, c->stream, g, f, ptr, qw_shift, bhat, y);    \
+        }                                                                                                                          \
+    } while (0)
+    if (kp == 0) FRONT_ROWS4(0);
+    else if (kp == 2) FRONT_ROWS4(2);
+    else if (kp == 4) FRONT_ROWS4(4);
+    else FRONT_ROWS4(8);
+#undef FRONT_ROWS4
 }
 
 static void front_launch_bwd(Ctx *c, const FrontDev &f, const FrontWork *ptr, int n, int nbt, int blk, const double *y, double *x) {
@@ -848,6 +983,37 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             }
         }
     };
+    // row kernel (k_front_fwd_rows): blocks of up to rows_wg rows that never span two members of a merged node (so that wk.lo is
+    // the first column of every row of the block) nor the separator / boundary rows; returns the longest column range a block stages
+    auto make_fwd_rows = [&](int k, int rows_wg, std::vector<FrontWork> &out) {
+        int lds_cols = 1;
+        for (int gi : by_band[(size_t)k]) {
+            const Group &G = groups[(size_t)gi];
+            const SweepNode sn = sweep_node(G);
+            const bool full = top_inv && k == nb - 1;
+            std::vector<std::array<int, 3>> segs;      // (first row, one past the last, first column)
+            if (full) segs.push_back({0, G.n, 0});
+            else {
+                for (int s : G.members)
+                    if (h->node_n[s] > 0) segs.push_back({off_in[(size_t)s], off_in[(size_t)s] + h->node_n[s], c0_in[(size_t)s]});
+                if (G.b > 0) segs.push_back({G.n, G.n + G.b, 0});
+            }
+            for (const auto &sg : segs)
+                for (int r = sg[0]; r < sg[1]; r += rows_wg) {
+                    FrontWork w{};
+                    w.nd = sn;
+                    w.first = r;
+                    w.pad = std::min(rows_wg, sg[1] - r);
+                    w.lo = sg[2];
+                    const int last = r + w.pad - 1;
+                    int jmax = last < G.n ? last + 1 : G.n;
+                    if (full) { w.end = G.n; jmax = G.n; }
+                    lds_cols = std::max(lds_cols, jmax - w.lo);
+                    out.push_back(w);
+                }
+        }
+        return lds_cols;
+    };
     auto make_bwd = [&](int k, int cb, std::vector<FrontWork> &out) {
         for (int gi : by_band[(size_t)k]) {
             const Group &G = groups[(size_t)gi];
@@ -885,6 +1051,10 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     // 4 rows per workgroup earlier (the planes are read once per workgroup, not per row).
     std::vector<int64_t> band_rows((size_t)nb, 0), band_cols((size_t)nb, 0);
     const bool two_modes = front_two_modes(c);
+    // lane groups of a wavefront in the row kernel: 64 / (lanes per row of modes); 0 = a row of modes is wider than a wavefront
+    const int lanes_row = two_modes ? d.TP / 2 : d.TP;
+    const int rows_groups = lanes_row <= 64 ? 64 / lanes_row : 0;
+    auto rows_per_wg = [&](int qs) { return std::max(1, ((256 / lanes_row) >> qs)); };
     for (int k = 0; k < nb; ++k) {
         for (int gi : by_band[(size_t)k]) {
             band_rows[(size_t)k] += groups[(size_t)gi].n + groups[(size_t)gi].b;
@@ -911,6 +1081,33 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         c->front_bwd_cb[k] = std::min(bcb, c->front_rb_max);
         c->front_fwd_nb[k] = fnb;
         c->front_bwd_nb[k] = bnb;
+        // Bands of short rows take the row kernel (k_front_fwd_rows): QW lane groups per row by the band's mean row length
+        // (rules from the DOTS_FRONT_TUNE tables of profiles/studies/shape_tuner.txt, round 3)
+        c->front_fwd_qw[k] = -1;
+        c->front_fwd_lds[k] = 0;
+        if (c->front_rows && rows_groups >= 1) {
+            double len = 0.0;      // columns a row of the band reads, summed
+            int longest = 1;
+            for (int gi : by_band[(size_t)k]) {
+                const Group &G = groups[(size_t)gi];
+                if (top_inv && k == nb - 1) { len += (double)G.n * G.n; longest = std::max(longest, G.n); continue; }
+                for (int s : G.members) {
+                    const double ns = h->node_n[s], w0 = off_in[(size_t)s] - c0_in[(size_t)s];
+                    len += ns * w0 + 0.5 * ns * (ns + 1);
+                    longest = std::max(longest, off_in[(size_t)s] + h->node_n[s] - c0_in[(size_t)s]);
+                }
+                len += (double)G.b * G.n;
+                if (G.b > 0) longest = std::max(longest, G.n);
+            }
+            const double mean = rows > 0 ? len / (double)rows : 0.0;
+            const bool fits = (size_t)longest * (size_t)(d.TP + FWD_ROWS_PAD) * sizeof(double) <= FWD_ROWS_LDS_MAX;
+            // (round-3 tables: with rows of <= ~30 columns one lane group per row wins by 10-60 %; on merged bands of 4+ planes the
+            // sixteen rows of a workgroup share ONE staged right-hand side: four groups per row draw level or win; elsewhere
+            // the fold kernels keep the longer rows)
+            int qs = mean <= FWD_ROWS_MEAN_MAX ? 0 : 2;
+            while ((1 << qs) > rows_groups) --qs;
+            if (fits && (c->front_rows >= 2 || mean <= FWD_ROWS_MEAN_MAX || (band_planes[(size_t)k] >= 4 && rows_groups >= 4))) c->front_fwd_qw[k] = qs;
+        }
     }
 
     // ---- device: the original tree, the factor, the merged blocks ----------------------------------------
@@ -1045,23 +1242,33 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     f.W = const_cast<double *>(w);
     c->front_bytes = 2.0 * entries_read * d.cg_ncol * sizeof(double);
     c->front_bytes_unmerged = 2.0 * entries_unmerged * d.cg_ncol * sizeof(double);
-    if (const char *e = getenv("DOTS_FRONT_CFG")) {      // "fwd:1024x2,256x4,...;bwd:..." one entry per band (A/B measurements)
+    if (const char *e = getenv("DOTS_FRONT_CFG")) {      // "fwd:1024x2,256x4,r1,...;bwd:..." one entry per band (A/B measurements); rQ = row kernel, Q lane groups per row
         const std::string spec(e);
-        for (int sweep = 0; sweep < 2; ++sweep) {
+        bool ok = spec.find("fwd:") != std::string::npos || spec.find("bwd:") != std::string::npos;
+        for (int sweep = 0; sweep < 2 && ok; ++sweep) {
             size_t pos = spec.find(sweep == 0 ? "fwd:" : "bwd:");
             if (pos == std::string::npos) continue;
             pos += 4;
             for (int k = 0; k < nb && pos < spec.size() && spec[pos] != ';'; ++k) {
-                int tnb = 0, trb = 0;
-                if (sscanf(spec.c_str() + pos, "%dx%d", &tnb, &trb) == 2 && (tnb == 256 || tnb == 1024) && (trb == 1 || trb == 2 || trb == 4)) {
+                int tnb = 0, trb = 0, q = 0;
+                if (sweep == 0 && sscanf(spec.c_str() + pos, "r%d", &q) == 1 && q >= 1 && q <= rows_groups && (q & (q - 1)) == 0) {
+                    int qs = 0;
+                    while ((1 << qs) < q) ++qs;
+                    c->front_fwd_qw[k] = qs;
+                } else if (sscanf(spec.c_str() + pos, "%dx%d", &tnb, &trb) == 2 && (tnb == 256 || tnb == 1024) && (trb == 1 || trb == 2 || trb == 4)) {
                     (sweep == 0 ? c->front_fwd_nb : c->front_bwd_nb)[k] = tnb;
                     (sweep == 0 ? c->front_fwd_rb : c->front_bwd_cb)[k] = trb;
+                    if (sweep == 0) c->front_fwd_qw[k] = -1;
+                } else if (spec[pos] != '-') {      // "-" keeps the rule's choice for the band
+                    ok = false;
+                    break;
                 }
                 pos = spec.find_first_of(",;", pos);
                 if (pos == std::string::npos || spec[pos] == ';') break;
                 ++pos;
             }
         }
+        if (!ok) { front_release(c); return bad("DOTS_FRONT_CFG: expected 'fwd:<entry>,...;bwd:<entry>,...' with entries 256xR, 1024xR (R = 1, 2, 4), rQ (forward: row kernel) or -"); }
     }
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx mod 8): every XCD gets one contiguous run of a launch's list, so
     // that the row blocks of a node, which read the same right-hand-side and plane rows, share an L2.  Measured (solve, us):
@@ -1121,14 +1328,42 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
                         (void)hipEventElapsedTime(&ms, e0, e1);
                         (void)hipFree(dl);
                         const double us = 1e3 * ms / reps;
-                        const bool cur = tnb == (sweep == 0 ? c->front_fwd_nb : c->front_bwd_nb)[k] && trb == (sweep == 0 ? c->front_fwd_rb : c->front_bwd_cb)[k];
+                        const bool cur = tnb == (sweep == 0 ? c->front_fwd_nb : c->front_bwd_nb)[k] && trb == (sweep == 0 ? c->front_fwd_rb : c->front_bwd_cb)[k] &&
+                                         !(sweep == 0 && c->front_fwd_qw[k] >= 0);
                         fprintf(stderr, " %dx%d %.2f%s", tnb, trb, us, cur ? "*" : "");
                         if (us < best) { best = us; bnb = tnb; brb = trb; }
                     }
-                fprintf(stderr, "  -> %dx%d\n", bnb, brb);
+                int bqs = -1;
+                if (sweep == 0) {
+                    for (int qs = 0; (1 << qs) <= rows_groups && qs <= 4; ++qs) {
+                        std::vector<FrontWork> list;
+                        const int lds_cols = make_fwd_rows(k, rows_per_wg(qs), list);
+                        if ((size_t)lds_cols * (size_t)(d.TP + FWD_ROWS_PAD) * sizeof(double) > FWD_ROWS_LDS_MAX || list.empty()) continue;
+                        deal(list, 0, by_band[(size_t)k].size());
+                        void *dl = nullptr;
+                        if (hipMalloc(&dl, sizeof(FrontWork) * list.size()) != hipSuccess) { ok = false; break; }
+                        (void)hipMemcpyAsync(dl, list.data(), sizeof(FrontWork) * list.size(), hipMemcpyHostToDevice, c->stream);
+                        const int reps = 20;
+                        for (int rep = -3; rep < reps; ++rep) {
+                            if (rep == 0) (void)hipEventRecord(e0, c->stream);
+                            front_launch_fwd_rows(c, f, (const FrontWork *)dl, (int)list.size(), qs, c->front_planes[k], lds_cols, vec[0], vec[1]);
+                        }
+                        (void)hipEventRecord(e1, c->stream);
+                        (void)hipEventSynchronize(e1);
+                        float ms = 0.f;
+                        (void)hipEventElapsedTime(&ms, e0, e1);
+                        (void)hipFree(dl);
+                        const double us = 1e3 * ms / reps;
+                        fprintf(stderr, " r%d %.2f%s", 1 << qs, us, c->front_fwd_qw[k] == qs ? "*" : "");
+                        if (us < best) { best = us; bqs = qs; }
+                    }
+                }
+                if (bqs >= 0) fprintf(stderr, "  -> r%d\n", 1 << bqs);
+                else fprintf(stderr, "  -> %dx%d\n", bnb, brb);
                 if (apply > 1 && bnb) {
                     (sweep == 0 ? c->front_fwd_nb : c->front_bwd_nb)[k] = bnb;
                     (sweep == 0 ? c->front_fwd_rb : c->front_bwd_cb)[k] = brb;
+                    if (sweep == 0) c->front_fwd_qw[k] = bqs;
                 }
             }
         if (e0) (void)hipEventDestroy(e0);
@@ -1142,7 +1377,14 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     for (int k = 0; k < nb; ++k) {
         c->front_fwd_ptr[k] = (int)fwd.size();
         c->front_bwd_ptr[k] = (int)bwd.size();
-        make_fwd(k, c->front_fwd_rb[k], fwd);
+        if (c->front_fwd_qw[k] >= 0) {
+            c->front_fwd_lds[k] = make_fwd_rows(k, rows_per_wg(c->front_fwd_qw[k]), fwd);
+            if ((size_t)c->front_fwd_lds[k] * (size_t)(d.TP + FWD_ROWS_PAD) * sizeof(double) > FWD_ROWS_LDS_MAX) {      // (a forced choice that does not fit)
+                fwd.resize((size_t)c->front_fwd_ptr[k]);
+                c->front_fwd_qw[k] = -1;
+            }
+        }
+        if (c->front_fwd_qw[k] < 0) make_fwd(k, c->front_fwd_rb[k], fwd);
         make_bwd(k, c->front_bwd_cb[k], bwd);
         deal(fwd, (size_t)c->front_fwd_ptr[k], by_band[(size_t)k].size());
         deal(bwd, (size_t)c->front_bwd_ptr[k], by_band[(size_t)k].size());
@@ -1164,8 +1406,9 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
     for (int l = 0; l < f.n_levels; ++l) {
         const int n = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
         // (a top band of explicit inverses writes the solution itself)
-        if (n > 0) front_launch_fwd(c, f, f.fwd_desc + c->front_fwd_ptr[l], n, c->front_fwd_nb[l], c->front_fwd_rb[l], c->front_planes[l], bhat,
-                                    (c->front_top_inverse && l == f.n_levels - 1) ? x : y);
+        double *out = (c->front_top_inverse && l == f.n_levels - 1) ? x : y;
+        if (n > 0 && c->front_fwd_qw[l] >= 0) front_launch_fwd_rows(c, f, f.fwd_desc + c->front_fwd_ptr[l], n, c->front_fwd_qw[l], c->front_planes[l], c->front_fwd_lds[l], bhat, out);
+        else if (n > 0) front_launch_fwd(c, f, f.fwd_desc + c->front_fwd_ptr[l], n, c->front_fwd_nb[l], c->front_fwd_rb[l], c->front_planes[l], bhat, out);
     }
     for (int l = f.n_levels - 1 - (c->front_top_inverse ? 1 : 0); l >= 0; --l) {
         const int n = c->front_bwd_ptr[l + 1] - c->front_bwd_ptr[l];

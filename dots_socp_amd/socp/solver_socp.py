@@ -304,6 +304,7 @@ class AlmSolver:
             else:
                 self.untimed_steps += 1
         else:       # the PCG waits for its convergence flags anyway: every iteration is timed
+            self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm)
             self._account(self.dev.step(1), kind)
 
     def _collect_step_times(self, wait=False):

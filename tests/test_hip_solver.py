@@ -242,7 +242,7 @@ def test_step_timers_cover_all_iterations():
         assert set(hist.steps_time) == {"Step 1-1 (Laplacian)", "Step 1-2 (SOC-Projection)", "Step 2+3 (Q & Lambda, Multiplier)"}
         sums[every] = sum(hist.steps_time.values())
         assert (hist.steps_time_note is None) == (every == "1")
-        assert sums[every] < hist.running_time
+        assert sums[every] < 1.15 * hist.running_time      # (an estimate of the device time of the steps; the run is device-bound)
     assert abs(sums["8"] - sums["1"]) < 0.15 * sums["1"], sums
     # (b) sphere10k-sized iterations take ~0.2 ms on the device against ~30 us of host work: the loop is device-bound
     geom, _ = meshes.example("sphere", level=5)
