@@ -44,6 +44,9 @@
 #ifndef DOTS_FRONT_UNROLL
 #define DOTS_FRONT_UNROLL 1
 #endif
+#ifndef DOTS_FRONT_U2
+#define DOTS_FRONT_U2 1      // steps of the dot product in flight with two-mode lanes (A/B: -DDOTS_FRONT_U2=2)
+#endif
 
 namespace dots {
 
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(NB) void k_front_fwd(FrontArgs g, FrontDev f, const
     // U steps of the dot product are loaded before the first is used (merged nodes have long rows: a step per
     // memory round trip would leave the workgroup waiting on latency).  One-mode lanes only: measured +1...7 % on the
     // merged small meshes, -2 % on the bandwidth-bound two-mode sweeps of torus100k (profiles/studies/band_cuts.txt)
-    constexpr int U = (!DOTS_FRONT_UNROLL || VEC > 1) ? 1 : ((1 + KP + RB) <= 6) ? 4 : (((1 + KP + RB) <= 12) ? 2 : 1);
+    constexpr int U = !DOTS_FRONT_UNROLL ? 1 : (VEC > 1 ? DOTS_FRONT_U2 : ((1 + KP + RB) <= 6) ? 4 : (((1 + KP + RB) <= 12) ? 2 : 1));
     if (live) {
         for (int j0 = wk.lo + q; j0 < jmax; j0 += U * Q) {
             Vd<VEC> wb[U], wp[U][KP > 0 ? KP : 1], fv[U][RB];
@@ -267,25 +270,6 @@ __global__ __launch_bounds__(256) void k_front_fwd_rows(FrontArgs g, FrontDev f,
     const int64_t plane = (int64_t)m << sh;
     const double *__restrict__ W0 = f.W + (nd.woff << sh) + a;         // plane 0; plane k is k * m rows further
     const int ldw = g.TP + FWD_ROWS_PAD;
-    if (live) {
-        for (int j = lo + grp; j < jmax; j += 256 >> shv) {
-            const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + j] : (int64_t)(nd.k0 + j);
-            Vd<VEC> w = vload<VEC>(bhat + (row << sh) + a);
-            if (KP > 0) {
-                Vd<VEC> wp[KP > 0 ? KP : 1];
-#pragma unroll
-                for (int k = 0; k < KP; ++k) wp[k] = vload<VEC>(W0 + k * plane + ((int64_t)j << sh));
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    double t = wp[0].v[c];
-#pragma unroll
-                    for (int k = 1; k < KP; ++k) t += wp[k].v[c];
-                    w.v[c] -= t;
-                }
-            }
-            vstore<VEC>(wsh + (j - lo) * ldw + a, w);
-        }
-    }
     // where an update row goes in the parent's plane, and what the children carried to it: loaded now, needed after the loop
     const bool store = part == 0 && rowok && live;
     const bool upd = store && i >= n;
@@ -295,32 +279,70 @@ __global__ __launch_bounds__(256) void k_front_fwd_rows(FrontArgs g, FrontDev f,
 #pragma unroll
         for (int k = 0; k < KP; ++k) cp[k] = vload<VEC>(W0 + k * plane + ((int64_t)i << sh));
     }
+    // The row's entries are loaded one BATCH of U columns ahead of their use: the first batch is in flight while w is staged
+    // (it does not depend on w), every later one while the batch before it is multiplied -- a row of 25 columns is 4-5 memory
+    // round trips instead of 8 (the launches of the middle heights run ONE round of workgroups: their time is that chain)
+    constexpr int U = 4;
+    const bool walk = rowok && live;
+    const int jend = !walk ? 0 : (wk.end > 0 ? wk.end : (i < n ? i + 1 : n));
+    const double *__restrict__ Fi = f.F + (nd.foff << sh) + a + (((int64_t)(walk ? i : row0) * n) << sh);
+    Vd<VEC> fv[U];
+    int j = lo + part;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int ju = j + u * QW;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) fv[u].v[c] = 0.0;
+        if (ju < jend) fv[u] = vload<VEC>(Fi + ((int64_t)ju << sh));
+    }
+    if (live) {
+        for (int js = lo + grp; js < jmax; js += 256 >> shv) {
+            const int64_t row = VMAP ? (int64_t)f.vmap[nd.k0 + js] : (int64_t)(nd.k0 + js);
+            Vd<VEC> w = vload<VEC>(bhat + (row << sh) + a);
+            if (KP > 0) {
+                Vd<VEC> wp[KP > 0 ? KP : 1];
+#pragma unroll
+                for (int k = 0; k < KP; ++k) wp[k] = vload<VEC>(W0 + k * plane + ((int64_t)js << sh));
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    double t = wp[0].v[c];
+#pragma unroll
+                    for (int k = 1; k < KP; ++k) t += wp[k].v[c];
+                    w.v[c] -= t;
+                }
+            }
+            vstore<VEC>(wsh + (js - lo) * ldw + a, w);
+        }
+    }
     __syncthreads();
     Vd<VEC> acc;
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc.v[c] = 0.0;
-    if (rowok && live) {
-        const int jend = wk.end > 0 ? wk.end : (i < n ? i + 1 : n);
-        const double *__restrict__ Fi = f.F + (nd.foff << sh) + a + (((int64_t)i * n) << sh);
-        const double *ws = wsh + a - lo * ldw;
-        constexpr int U = 4;
-        int j = lo + part;
-        for (; j + (U - 1) * QW < jend; j += U * QW) {
-            Vd<VEC> fv[U], wv[U];
+    const double *ws = wsh + a - lo * ldw;
+    while (j < jend) {
+        Vd<VEC> nx[U], wv[U];
+        const int jn = j + U * QW;
 #pragma unroll
-            for (int u = 0; u < U; ++u) fv[u] = vload<VEC>(Fi + ((int64_t)(j + u * QW) << sh));
+        for (int u = 0; u < U; ++u) {
+            const int ju = jn + u * QW;
 #pragma unroll
-            for (int u = 0; u < U; ++u) wv[u] = vload<VEC>(ws + (j + u * QW) * ldw);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) acc.v[c] += fv[u].v[c] * wv[u].v[c];
+            for (int c = 0; c < VEC; ++c) nx[u].v[c] = 0.0;
+            if (ju < jend) nx[u] = vload<VEC>(Fi + ((int64_t)ju << sh));
         }
-        for (; j < jend; j += QW) {
-            const Vd<VEC> fv = vload<VEC>(Fi + ((int64_t)j << sh)), wv = vload<VEC>(ws + j * ldw);
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) acc.v[c] += fv.v[c] * wv.v[c];
+        for (int u = 0; u < U; ++u) {
+            const int ju = j + u * QW;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) wv[u].v[c] = 0.0;
+            if (ju < jend) wv[u] = vload<VEC>(ws + ju * ldw);
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) acc.v[c] += fv[u].v[c] * wv[u].v[c];
+#pragma unroll
+        for (int u = 0; u < U; ++u) fv[u] = nx[u];
+        j = jn;
     }
     for (int o = 1 << shv; o < (1 << (shv + qw_shift)); o <<= 1) {
 #pragma unroll
@@ -372,7 +394,7 @@ __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const
         for (int c = 0; c < VEC; ++c) acc[r].v[c] = 0.0;
         co[r] = (int64_t)(r < nc ? col0 + r : col0) << sh;
     }
-    constexpr int U = (!DOTS_FRONT_UNROLL || VEC > 1) ? 1 : ((1 + RB) <= 4) ? 4 : 2;      // as in the forward sweep
+    constexpr int U = !DOTS_FRONT_UNROLL ? 1 : (VEC > 1 ? DOTS_FRONT_U2 : ((1 + RB) <= 4) ? 4 : 2);      // as in the forward sweep
     if (live) {
         // rows of the separators: y.  Column i of L^-1 is zero above the diagonal: start at the block's first column
 #pragma unroll
@@ -520,6 +542,13 @@ __global__ __launch_bounds__(256) void k_top_inverse(TopInvArgs g) {
         for (; k < n; ++k) s0 += L[((int64_t)k * n + i) << sh] * L[((int64_t)k * n + j) << sh];
         S[e << sh] = s0 + s1;
     }
+}
+
+// reads `n` doubles and writes nothing (the sum is never NaN-compared true): evicts the caches without leaving dirty lines (tuner)
+__global__ __launch_bounds__(256) void k_flush_read(const double *__restrict__ x, int64_t n, double *sink) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i];
+    if (s == 1.2345e300) *sink = s;
 }
 
 // two modes per lane (16-byte loads, half the waves).  Round 1 (one launch per tree height): +6 % at torus100k, +13 % at T = 127,
@@ -1299,6 +1328,44 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         ok = ok && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
         const int apply = c->front_tune;
+        // A factor larger than the Infinity Cache streams from HBM in the real solve; a launch repeated back to back would find its
+        // band (60-130 MB) in the cache.  There every timed launch is preceded by a read sweep over 512 MB (cold caches, no dirty lines, one event pair per
+        // launch); small factors ARE cache-resident in the real solve and are timed back to back.
+        const bool cold = c->front_bytes > 400.0e6;
+        void *flushbuf = nullptr;
+        const size_t flush_bytes = (size_t)512 << 20;
+        if (cold && ok) {
+            ok = hipMalloc(&flushbuf, flush_bytes) == hipSuccess;
+            if (ok) { tmp.push_back(flushbuf); ok = hipMemsetAsync(flushbuf, 0, flush_bytes, c->stream) == hipSuccess; }
+        }
+        auto time_us = [&](const std::function<void()> &launch) -> double {
+            if (!cold) {
+                const int reps = 20;
+                for (int rep = -3; rep < reps; ++rep) {
+                    if (rep == 0) (void)hipEventRecord(e0, c->stream);
+                    launch();
+                }
+                (void)hipEventRecord(e1, c->stream);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                return 1e3 * ms / reps;
+            }
+            const int reps = 6;
+            double total = 0.0;
+            for (int rep = -1; rep < reps; ++rep) {
+                hipLaunchKernelGGL(k_flush_read, dim3(4096), dim3(256), 0, c->stream, (const double *)flushbuf, (int64_t)(flush_bytes / sizeof(double)), (double *)flushbuf);
+                (void)hipEventRecord(e0, c->stream);
+                launch();
+                (void)hipEventRecord(e1, c->stream);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (rep >= 0) total += ms;
+            }
+            return 1e3 * total / reps;
+        };
+        if (cold) fprintf(stderr, "[front tune] cold caches: every timed launch follows a read sweep over 512 MB\n");
         for (int k = 0; k < nb && ok; ++k)
             for (int sweep = 0; sweep < 2 && ok; ++sweep) {
                 if (sweep == 1 && top_inv && k == nb - 1) continue;      // no backward launch there
@@ -1316,18 +1383,11 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
                         void *dl = nullptr;
                         if (hipMalloc(&dl, sizeof(FrontWork) * list.size()) != hipSuccess) { ok = false; break; }
                         (void)hipMemcpyAsync(dl, list.data(), sizeof(FrontWork) * list.size(), hipMemcpyHostToDevice, c->stream);
-                        const int reps = 20;
-                        for (int rep = -3; rep < reps; ++rep) {
-                            if (rep == 0) (void)hipEventRecord(e0, c->stream);
+                        const double us = time_us([&]() {
                             if (sweep == 0) front_launch_fwd(c, f, (const FrontWork *)dl, (int)list.size(), tnb, trb, c->front_planes[k], vec[0], vec[1]);
                             else front_launch_bwd(c, f, (const FrontWork *)dl, (int)list.size(), tnb, trb, vec[1], vec[2]);
-                        }
-                        (void)hipEventRecord(e1, c->stream);
-                        (void)hipEventSynchronize(e1);
-                        float ms = 0.f;
-                        (void)hipEventElapsedTime(&ms, e0, e1);
+                        });
                         (void)hipFree(dl);
-                        const double us = 1e3 * ms / reps;
                         const bool cur = tnb == (sweep == 0 ? c->front_fwd_nb : c->front_bwd_nb)[k] && trb == (sweep == 0 ? c->front_fwd_rb : c->front_bwd_cb)[k] &&
                                          !(sweep == 0 && c->front_fwd_qw[k] >= 0);
                         fprintf(stderr, " %dx%d %.2f%s", tnb, trb, us, cur ? "*" : "");
@@ -1343,17 +1403,8 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
                         void *dl = nullptr;
                         if (hipMalloc(&dl, sizeof(FrontWork) * list.size()) != hipSuccess) { ok = false; break; }
                         (void)hipMemcpyAsync(dl, list.data(), sizeof(FrontWork) * list.size(), hipMemcpyHostToDevice, c->stream);
-                        const int reps = 20;
-                        for (int rep = -3; rep < reps; ++rep) {
-                            if (rep == 0) (void)hipEventRecord(e0, c->stream);
-                            front_launch_fwd_rows(c, f, (const FrontWork *)dl, (int)list.size(), qs, c->front_planes[k], lds_cols, vec[0], vec[1]);
-                        }
-                        (void)hipEventRecord(e1, c->stream);
-                        (void)hipEventSynchronize(e1);
-                        float ms = 0.f;
-                        (void)hipEventElapsedTime(&ms, e0, e1);
+                        const double us = time_us([&]() { front_launch_fwd_rows(c, f, (const FrontWork *)dl, (int)list.size(), qs, c->front_planes[k], lds_cols, vec[0], vec[1]); });
                         (void)hipFree(dl);
-                        const double us = 1e3 * ms / reps;
                         fprintf(stderr, " r%d %.2f%s", 1 << qs, us, c->front_fwd_qw[k] == qs ? "*" : "");
                         if (us < best) { best = us; bqs = qs; }
                     }
@@ -1373,18 +1424,22 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         (void)hipStreamSynchronize(c->stream);
         for (void *p2 : tmp) (void)hipFree(p2);
     }
+    // (Tried in round 3 and rejected: the independent subtrees below the top of the tree on 2 or 4 streams, so that one stream's
+    // ramp-up and drain overlap another's streaming -- launches from several streams do not overlap here, every launch costs
+    // ~10 us more: sphere10k solve 85 -> 169 -> 272 us, torus100k 753 -> 804 -> 1061 us; profiles/studies/r03_lanes_experiment.txt)
     std::vector<FrontWork> fwd, bwd;
     for (int k = 0; k < nb; ++k) {
         c->front_fwd_ptr[k] = (int)fwd.size();
         c->front_bwd_ptr[k] = (int)bwd.size();
         if (c->front_fwd_qw[k] >= 0) {
             c->front_fwd_lds[k] = make_fwd_rows(k, rows_per_wg(c->front_fwd_qw[k]), fwd);
-            if ((size_t)c->front_fwd_lds[k] * (size_t)(d.TP + FWD_ROWS_PAD) * sizeof(double) > FWD_ROWS_LDS_MAX) {      // (a forced choice that does not fit)
-                fwd.resize((size_t)c->front_fwd_ptr[k]);
-                c->front_fwd_qw[k] = -1;
+            if ((size_t)c->front_fwd_lds[k] * (size_t)(d.TP + FWD_ROWS_PAD) * sizeof(double) > FWD_ROWS_LDS_MAX) {
+                front_release(c);
+                return bad("DOTS_FRONT_CFG: the row kernel does not fit a band it was forced on (its right-hand side exceeds the LDS budget)");
             }
+        } else {
+            make_fwd(k, c->front_fwd_rb[k], fwd);
         }
-        if (c->front_fwd_qw[k] < 0) make_fwd(k, c->front_fwd_rb[k], fwd);
         make_bwd(k, c->front_bwd_cb[k], bwd);
         deal(fwd, (size_t)c->front_fwd_ptr[k], by_band[(size_t)k].size());
         deal(bwd, (size_t)c->front_bwd_ptr[k], by_band[(size_t)k].size());

@@ -263,7 +263,7 @@ def test_step_timers_cover_all_iterations():
     steps = sum(alm.run_history.steps_time.values()) - t_before
     alm.close()
     # the KKT kernels, the penalty divisions and the host's decisions on read-back iterations are not under a step timer (as in the reference)
-    assert 0.70 * wall < steps < 1.02 * wall, (steps, wall)
+    assert 0.70 * wall < steps < 1.10 * wall, (steps, wall)
 
 
 def test_mailbox_fallback_never_returns_stale_sums():
