@@ -30,7 +30,7 @@ EXPORTS = [
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
     "dots_slab_elems", "dots_slab_set_buffers", "dots_slab_stage", "dots_kkt_sums", "dots_kkt_sums_device", "dots_debug_counter", "dots_kkt_combine", "dots_objective_sums",
     "dots_objective_combine", "dots_front_launches", "dots_front_info", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_step_times", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
-    "dots_symbolic_build", "dots_symbolic_front_rows", "dots_symbolic_copy", "dots_symbolic_free",
+    "dots_patch_order", "dots_symbolic_build", "dots_symbolic_front_rows", "dots_symbolic_copy", "dots_symbolic_free",
 ]
 
 
@@ -51,6 +51,7 @@ class ProblemDesc(C.Structure):
         ("mu0", _f64p), ("mu1", _f64p), ("perm_vert", _i32p), ("perm_tri", _i32p),
         ("time_modes", _f64p), ("time_eigs", _f64p),
         ("slab_begin", C.c_int32), ("slab_count", C.c_int32), ("slab_stride", C.c_int32), ("reserved", C.c_int32),
+        ("patch_order", _i32p),
     ]
 
 
@@ -120,7 +121,7 @@ SLAB_SIZES = {"vertex_halo": 0, "b_chunk": 1, "x_chunk": 2, "triangle_halo": 3}
 # not in this list, or a value outside a switch's domain, is an error: a typo must not silently select the default.
 KNOWN_ENV = {
     # read by the library (csrc/dots_api.hip: env_int)
-    "DOTS_CG_STAGE_LDS", "DOTS_MG_TAIL_ROWS", "DOTS_SOC_WITH_RHS", "DOTS_QL_TWO", "DOTS_KKT_TWO", "DOTS_RHS_TWO", "DOTS_SPIN_FETCH",
+    "DOTS_CG_STAGE_LDS", "DOTS_MG_TAIL_ROWS", "DOTS_SOC_WITH_RHS", "DOTS_QL_TWO", "DOTS_KKT_TWO", "DOTS_RHS_TWO", "DOTS_RHS_TILES", "DOTS_SPIN_FETCH",
     "DOTS_FRONT_VEC2", "DOTS_FRONT_RB", "DOTS_FRONT_ROWS", "DOTS_FRONT_XCD", "DOTS_FRONT_TUNE", "DOTS_FRONT_CFG", "DOTS_MAIL_TEST_DROP",
     "DOTS_MAIL_SPINS", "DOTS_ND_PCA_MIN",
     # read by the host side
@@ -244,6 +245,7 @@ def load():
     lib.dots_stream_wait.argtypes = [vp, vp, C.c_int]
     i64p = C.POINTER(C.c_int64)
     lib.dots_tree_build.argtypes = [C.c_int32, _i32p, _i32p, _f64p, C.c_int32, C.POINTER(vp)]
+    lib.dots_patch_order.argtypes = [C.c_int32, _f64p, C.c_int32, _i32p]
     lib.dots_tree_nodes.argtypes = [vp]
     lib.dots_tree_nodes.restype = C.c_int64
     lib.dots_tree_copy.argtypes = [vp, i64p, i64p, _i32p, _i32p, _i32p]

@@ -162,7 +162,40 @@ struct Dissector {
 
 }  // namespace
 
+namespace {
+// recursive coordinate bisection of the points ids[lo:hi): longest side of the bounding box, cut at a multiple of `unit`
+void patch_bisect(const double *xyz, int32_t *ids, int lo, int hi, int unit) {
+    const int m = hi - lo;
+    if (m <= unit) return;
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int i = lo; i < hi; ++i)
+        for (int c = 0; c < 3; ++c) {
+            const double x = xyz[3 * (size_t)ids[i] + c];
+            mn[c] = std::min(mn[c], x);
+            mx[c] = std::max(mx[c], x);
+        }
+    int ax = 0;
+    for (int c = 1; c < 3; ++c)
+        if (mx[c] - mn[c] > mx[ax] - mn[ax]) ax = c;
+    int half = std::max(unit, (m / 2 + unit - 1) / unit * unit);
+    if (half >= m) half = m - 1;
+    std::nth_element(ids + lo, ids + lo + half, ids + hi, [&](int32_t a, int32_t b) {
+        const double xa = xyz[3 * (size_t)a + ax], xb = xyz[3 * (size_t)b + ax];
+        return xa != xb ? xa < xb : a < b;
+    });
+    patch_bisect(xyz, ids, lo, lo + half, unit);
+    patch_bisect(xyz, ids, lo + half, hi, unit);
+}
+}  // namespace
+
 extern "C" {
+
+int dots_patch_order(int32_t n_vertices, const double *xyz, int32_t unit, int32_t *order) {
+    if (n_vertices < 1 || !xyz || unit < 1 || !order) { dots::set_error("patch_order: bad argument"); return DOTS_ERR_ARGUMENT; }
+    std::iota(order, order + n_vertices, 0);
+    patch_bisect(xyz, order, 0, n_vertices, unit);
+    return 0;
+}
 
 int dots_tree_build(int32_t n_vertices, const int32_t *indptr, const int32_t *indices, const double *xyz, int32_t leaf, dots_tree **out) {
     if (n_vertices < 1 || !indptr || !indices || !xyz || leaf < 1 || !out) { dots::set_error("tree_build: bad argument"); return DOTS_ERR_ARGUMENT; }

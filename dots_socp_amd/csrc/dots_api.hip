@@ -198,6 +198,40 @@ static int build(Ctx *c, const dots_problem_desc *p) {
         for (int i = 0; i <= d.T; ++i) sig[i] = p->time_eigs[i];
         UP(sigma, sig.data(), tpg);
     }
+    // patch tiles of the right-hand-side / projection launch (k_rhs_soc_tiles: one GPU, T + 1 < 64)
+    if (p->patch_order && !sharded && p->lap_solver == DOTS_LAP_MODAL_PCG && tpg >= 4 && tpg <= 32) {
+        TileDev &tl = c->tiles;
+        tl.VTL = 512 / tpg;
+        tl.n_tiles = (V + tl.VTL - 1) / tl.VTL;
+        std::vector<int> tv((size_t)tl.n_tiles * tl.VTL, -1), tptr((size_t)tl.n_tiles + 1, 0), ttri, cloc((size_t)nC, 0), stamp((size_t)F, -1), pos((size_t)F, 0);
+        std::vector<char> seen((size_t)V, 0);
+        for (int i = 0; i < V; ++i) {
+            const int v = p->patch_order[i];
+            if (v < 0 || v >= V || seen[(size_t)v]) { set_error("patch_order is not a permutation of the vertices"); return DOTS_ERR_ARGUMENT; }
+            seen[(size_t)v] = 1;
+            tv[(size_t)i] = v;
+        }
+        for (int t = 0; t < tl.n_tiles; ++t) {
+            int count = 0;
+            for (int k = 0; k < tl.VTL; ++k) {
+                const int v = tv[(size_t)t * tl.VTL + k];
+                if (v < 0) continue;
+                for (int j = p->corner_ptr[v]; j < p->corner_ptr[v + 1]; ++j) {
+                    const int f = p->corner_idx[j] / 3;
+                    if (stamp[(size_t)f] != t) { stamp[(size_t)f] = t; pos[(size_t)f] = count++; ttri.push_back(f); }
+                    cloc[(size_t)j] = pos[(size_t)f];
+                }
+            }
+            tptr[(size_t)t + 1] = (int)ttri.size();
+            tl.ntri_max = std::max(tl.ntri_max, count);
+        }
+        if (ttri.empty()) ttri.push_back(0);
+        UP(tiles_vertex, tv.data(), tv.size());
+        UP(tiles_tri_ptr, tptr.data(), tptr.size());
+        UP(tiles_tri, ttri.data(), ttri.size());
+        UP(tiles_c_loc, cloc.data(), cloc.size());
+        tl.vertex = d.tiles_vertex; tl.tri_ptr = d.tiles_tri_ptr; tl.tri = d.tiles_tri; tl.c_loc = d.tiles_c_loc;
+    }
 #undef UP
 
     double **state[12] = {&d.phi, &d.A, &d.B, &d.lam, &d.zf, &d.zm, &d.ze, &d.mu, &d.E, &d.bf, &d.bm, &d.be};
@@ -459,6 +493,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
         ok &= env_int("DOTS_QL_TWO", 0, 1, &c->ql_two);
         ok &= env_int("DOTS_KKT_TWO", 0, 1, &c->kkt_two);
         ok &= env_int("DOTS_RHS_TWO", 0, 1, &c->rhs_two);
+        ok &= env_int("DOTS_RHS_TILES", 0, 1, &c->rhs_tiles);
         ok &= env_int("DOTS_SPIN_FETCH", 0, 1, &c->spin_fetch);
         ok &= env_int("DOTS_FRONT_VEC2", 0, 3, &c->front_vec2);      // 0 never, 1 / 2 wherever the pitch allows (default), 3 only where bandwidth-bound
         ok &= env_int("DOTS_FRONT_RB", 1, 4, &c->front_rb_max);

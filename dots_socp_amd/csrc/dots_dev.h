@@ -70,6 +70,7 @@ struct Dev {
     const double *kdiag;     // [V] diagonal of K
     const double *mu0, *mu1; // [V]
     const int *perm_v, *perm_f;
+    const int *tiles_vertex, *tiles_tri_ptr, *tiles_tri, *tiles_c_loc;   // owned arrays behind Ctx::tiles
     const double *Q;         // [(T+1)^2] or null
     const double *Qpad, *QpadT;  // [TP][TP] Q and its transpose, zero padded (operands of the MFMA transform)
     const double *sigma;     // [T+1] or null
@@ -161,6 +162,16 @@ struct MergeMember {
     int ch[2];                // its children inside the band by pull map (index of the member record, -1: none or below the band)
     int pad;
 };
+// Vertex tiles of the right-hand-side / projection launch cut from dots_problem_desc.patch_order (compact patches of the surface)
+// with the distinct triangles each tile touches (k_rhs_soc_tiles stages their rows of B, E in LDS).
+struct TileDev {
+    int n_tiles = 0, VTL = 0, ntri_max = 0;
+    const int *vertex = nullptr;     // [n_tiles][VTL] device vertices, -1 = padding
+    const int *tri_ptr = nullptr;    // [n_tiles + 1]
+    const int *tri = nullptr;        // the distinct triangles of every tile
+    const int *c_loc = nullptr;      // [3F] per corner-list entry: position of its triangle in its vertex's tile
+};
+
 struct FrontDev {
     int n_nodes = 0, n_levels = 0;        // original nodes; launches per sweep (= bands of tree heights)
     const FrontNode *nodes = nullptr;     // original tree (factorisation)
@@ -189,6 +200,7 @@ constexpr int FLAG_ITERS = CgScalOffsets::NCMAX;
 constexpr int FLAG_TOTAL = CgScalOffsets::NCMAX + 8;
 
 struct Ctx;
+bool rhs_on_tiles(const Ctx *c);    // the right-hand-side / projection launch runs on patch tiles (k_rhs_soc_tiles)
 
 // ---- launch wrappers implemented in the kernel files (all asynchronous on ctx stream) ----
 int launch_soc_projection(Ctx *c, int zmid_mode = 0, bool with_inverse = false);   // 0: write z_mid; 1: write only the cone multiplier; with_inverse: extra workgroups do the modes -> time transform of phi
@@ -277,6 +289,8 @@ struct Ctx {
     int kkt_two = 1;              // KKT sums with two nodes per lane (one GPU; DOTS_KKT_TWO=0: one)
     int ql_two = 1;               // steps 2+3 with two nodes per lane (DOTS_QL_TWO=0: one, for A/B measurements)
     int rhs_two = 1;              // right-hand side + projection with two time columns per lane (DOTS_RHS_TWO=0: one)
+    int rhs_tiles = 0;            // ... on patch tiles with the triangle rows staged in LDS (DOTS_RHS_TILES=1; measured slower: off by default)
+    TileDev tiles{};
     // DOTS_STEP_TIMED: phase events of enqueue-only steps, collected later by dots_step_times (no host wait in the loop)
     static constexpr int TIME_SLOTS = 64;
     hipEvent_t tev[TIME_SLOTS][5]{};  // created on first use
@@ -459,7 +473,7 @@ __device__ __forceinline__ void stage_q_chunk(const Dev &d, const double *Q, dou
 }
 template <bool FWD, int NB = BLOCK>
 __device__ __forceinline__ void modes_from_tile(const Dev &d, const double *Q, const double *xs, double *Qs, int IC, int v0, double *__restrict__ y,
-                                                int out_shift = -1, int j0 = 0, int jn = 1 << 30, bool staged0 = false) {
+                                                int out_shift = -1, int j0 = 0, int jn = 1 << 30, bool staged0 = false, const int *__restrict__ vids = nullptr) {
     if (out_shift < 0) out_shift = d.tp_shift;
     const int n = d.T + 1, TP = d.TP, TPp = TP + 1, tid = threadIdx.x;
     const int j = tid & (TP - 1), g = tid >> d.tp_shift, G = NB >> d.tp_shift;
@@ -485,7 +499,9 @@ __device__ __forceinline__ void modes_from_tile(const Dev &d, const double *Q, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int vl = g + r * G;
-            if (vl < d.VT && v0 + vl < d.V) y[((int64_t)(v0 + vl) << out_shift) + (j - j0)] = acc[r];
+            if (vl >= d.VT) continue;
+            const int vv = vids ? vids[vl] : v0 + vl;       // (vids: the tile's own vertex list, -1 = padding)
+            if (vv >= 0 && vv < d.V) y[((int64_t)vv << out_shift) + (j - j0)] = acc[r];
         }
     }
 }

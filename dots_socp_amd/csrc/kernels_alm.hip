@@ -96,7 +96,11 @@ __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double s
 // The projection of the intervals t and t + 1 (t even) of a vertex by ONE lane, multiplier only (one GPU: every node is held
 // here): B and the s = 0 entries of both intervals sit in one aligned 16-byte word per row, 15 loads per corner instead of 24;
 // half the waves for the same bytes (see k_q_lambda_mult_triangle2).  Interval for interval the arithmetic of soc_element.
-__device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double sz, double cd) {
+// STAGED: the rows of B come from LDS (`rows`: the tile's distinct triangles, [position][c][ldr]; `c_loc`: the position of a
+// corner-list entry's triangle) instead of from memory (k_rhs_soc_tiles): the same values, the same arithmetic.
+template <bool STAGED>
+__device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double sz, double cd, const double *rows = nullptr, int ldr = 0,
+                                             const int *__restrict__ c_loc = nullptr) {
     const double sB = sz * INV_SQRT3;
     const int iv = idxV(d, v, t);
     const bool two = t + 1 < d.ni;                 // the second interval exists (T odd: not for the last pair)
@@ -110,10 +114,16 @@ __device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double 
         double b2[3], m1a[3], m1b[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            bt[c] = ld2(d.B + idxF(d, f, c, t));
+            if (STAGED) {
+                const double *rw = rows + (c_loc[j] * 3 + c) * ldr + t;
+                bt[c] = ld2(rw);
+                b2[c] = two ? rw[2] : 0.0;
+            } else {
+                bt[c] = ld2(d.B + idxF(d, f, c, t));
+                b2[c] = two ? d.B[idxF(d, f, c, t + 2)] : 0.0;
+            }
             m0[c] = ld2(d.bm + idxM(d, fk, 0, c, t));
             m1a[c] = d.bm[idxM(d, fk, 1, c, t)];
-            b2[c] = two ? d.B[idxF(d, f, c, t + 2)] : 0.0;
             m1b[c] = two ? d.bm[idxM(d, fk, 1, c, t + 1)] : 0.0;
         }
 #pragma unroll
@@ -333,7 +343,10 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double ep
 
 // The right-hand side at the nodes t and t + 1 (t even) of a vertex by one lane (one GPU), node for node the arithmetic of
 // rhs_value: B and E of both nodes in one 16-byte word per row.
-__device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r, double eps, double (&out)[2]) {
+// STAGED: B - E of the tile's distinct triangles comes from LDS (see soc_element2).
+template <bool STAGED>
+__device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r, double eps, double (&out)[2], const double *rows = nullptr, int ldr = 0,
+                                           const int *__restrict__ c_loc = nullptr) {
     const int iv = idxV(d, v, t);
     const double m = d.mass_v[v];
     const double ih = 1.0 / d.h;
@@ -349,15 +362,19 @@ __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r,
         double ga[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const int64_t i = idxF(d, f, c, t);
             ga[c] = d.c_gA[j * 3 + c];
-            b[c] = ld2(d.B + i);
-            e[c] = ld2(d.E + i);
+            if (STAGED) {
+                b[c] = ld2(rows + (c_loc[j] * 3 + c) * ldr + t);      // B - E, subtracted when it was staged
+            } else {
+                const int64_t i = idxF(d, f, c, t);
+                b[c] = ld2(d.B + i);
+                e[c] = ld2(d.E + i);
+            }
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            ds[0] += ga[c] * (b[c].v[0] - e[c].v[0]);
-            ds[1] += ga[c] * (b[c].v[1] - e[c].v[1]);
+            ds[0] += ga[c] * (STAGED ? b[c].v[0] : b[c].v[0] - e[c].v[0]);
+            ds[1] += ga[c] * (STAGED ? b[c].v[1] : b[c].v[1] - e[c].v[1]);
         }
     }
 #pragma unroll
@@ -378,7 +395,7 @@ __global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double 
         const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
         if (st >= d.n_vtiles) return;
         const int v = st * d.VT + vl;
-        if (v < d.V && t < d.ni) soc_element2(d, v, t, sz, cd);
+        if (v < d.V && t < d.ni) soc_element2<false>(d, v, t, sz, cd);
         return;
     }
     extern __shared__ double tm_lds[];
@@ -392,11 +409,69 @@ __global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double 
     for (int ee = e; ee < TILE_ELEMS; ee += 2 * RHS_NB2) {       // (one pass: TILE_ELEMS = 2 * RHS_NB2)
         const int vv = ee >> d.tp_shift, tt = ee & (TP - 1);
         double b[2] = {0.0, 0.0};
-        if (v0 + vv < d.V && tt < n) rhs_value2(d, v0 + vv, tt, r, eps, b);
+        if (v0 + vv < d.V && tt < n) rhs_value2<false>(d, v0 + vv, tt, r, eps, b);
         xs[vv * TPp + tt] = b[0];
         xs[vv * TPp + tt + 1] = tt + 1 < n ? b[1] : 0.0;
     }
     modes_from_tile<true, RHS_NB2>(d, d.Q, xs, Qs, IC, v0, bhat, -1, 0, 1 << 30, true);
+}
+
+// The right-hand side + projection launch on PATCH tiles (dots_problem_desc.patch_order): a workgroup of 256 threads takes
+// TILE2 / TP vertices of a compact patch of the surface (two time columns per lane) and stages the rows of B of the patch's
+// DISTINCT triangles in LDS once; the projection walks its corner lists against them (beta_mid streams from memory, each
+// entry once); then E is subtracted in place and the right-hand side walks the same lists against B - E, followed at once by
+// the time-mode transform of the tile.  The corner walks of k_rhs_modes2 fetch the three rows of B (and of E) of a triangle
+// once per corner VERTEX; the caches catch little of that beside the beta_mid stream (PMC at torus100k: 2.25 GB read for
+// 1.50 GB algorithmic).  Here a triangle's rows are read once per tile that touches it (~1.6 tiles), and B serves both halves.
+// Vertex for vertex and corner for corner the arithmetic of rhs_value2 / soc_element2: results are bit-identical.
+constexpr int TILE2 = 512, TILE2_NB = 256;
+template <bool WITH_SOC>
+__global__ __launch_bounds__(TILE2_NB) void k_rhs_soc_tiles(Dev d, TileDev tl, double r, double eps, double *__restrict__ bhat, int IC, double sz, double cd) {
+    extern __shared__ double tm_lds[];
+    const int n = d.T + 1, TP = d.TP, TPp = TP + 1, ldr = TP + 2;
+    double *Qs = tm_lds;                          // [IC][TP]
+    double *xs = tm_lds + IC * TP;                // [VTL][TPp]
+    double *rows = xs + tl.VTL * TPp + (((tl.VTL * TPp) & 1) ? 1 : 0);      // [distinct triangles][3][ldr], 16-byte aligned
+    const int tile = xcd_tile(blockIdx.x, tl.n_tiles);
+    if (tile >= tl.n_tiles) return;
+    const int *__restrict__ tv = tl.vertex + tile * tl.VTL;
+    const int t0 = tl.tri_ptr[tile], nrow = 3 * (tl.tri_ptr[tile + 1] - t0);
+    const int lr = TP >> 1, tid = threadIdx.x;    // lanes per row (two columns each)
+    const int ra = (tid & (lr - 1)) * 2, r0 = tid / lr, rstep = TILE2_NB / lr;
+    for (int row = r0; row < nrow; row += rstep) {
+        const int f = tl.tri[t0 + row / 3], c = row - 3 * (row / 3);
+        D2 b = ld2(d.B + idxF(d, f, c, ra));
+        if (!WITH_SOC) {
+            const D2 e = ld2(d.E + idxF(d, f, c, ra));
+            b.v[0] -= e.v[0];
+            b.v[1] -= e.v[1];
+        }
+        st2(rows + row * ldr + ra, b);
+    }
+    stage_q_chunk<true, TILE2_NB>(d, d.Q, Qs, 0, min(IC, n));
+    __syncthreads();
+    const int e2 = 2 * tid, vl = e2 >> d.tp_shift, t = e2 & (TP - 1);
+    const int v = tv[vl];
+    if (WITH_SOC) {
+        if (v >= 0 && t < d.ni) soc_element2<true>(d, v, t, sz, cd, rows, ldr, tl.c_loc);
+        __syncthreads();
+        for (int row = r0; row < nrow; row += rstep) {      // (every thread updates the entries it staged itself)
+            const int f = tl.tri[t0 + row / 3], c = row - 3 * (row / 3);
+            const D2 e = ld2(d.E + idxF(d, f, c, ra));
+            D2 b = ld2(rows + row * ldr + ra);
+            b.v[0] -= e.v[0];
+            b.v[1] -= e.v[1];
+            st2(rows + row * ldr + ra, b);
+        }
+        __syncthreads();
+    }
+    double b[2] = {0.0, 0.0};
+    if (v >= 0 && t < n) rhs_value2<true>(d, v, t, r, eps, b, rows, ldr, tl.c_loc);
+    xs[vl * TPp + t] = b[0];
+    xs[vl * TPp + t + 1] = t + 1 < n ? b[1] : 0.0;
+    Dev dt = d;
+    dt.VT = tl.VTL;
+    modes_from_tile<true, TILE2_NB>(dt, d.Q, xs, Qs, IC, 0, bhat, -1, 0, 1 << 30, true, tv);
 }
 
 // T + 1 >= 64: 32 vertices per workgroup, the transform on the matrix cores.
@@ -421,12 +496,42 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, doub
     modes_from_tile_mfma<RHS_NB / 64>(d, d.Qpad, xs_m, v0, bhat);
 }
 
+constexpr size_t RHS_TILES_LDS_MAX = 80 * 1024;      // two workgroups per CU stay resident
+// LDS of k_rhs_soc_tiles: Q chunk + the tile of right-hand-side values + the staged triangle rows
+static size_t rhs_tiles_lds(const Dev &d, const TileDev &tl) {
+    const size_t xs = (size_t)tl.VTL * (d.TP + 1);
+    return sizeof(double) * ((size_t)time_modes_chunk(d) * d.TP + xs + (xs & 1) + (size_t)tl.ntri_max * 3 * (d.TP + 2));
+}
+// DOTS_RHS_TILES=1 (default 0).  Measured in round 3 (profiles/studies/r03_rhs_tiles.txt): the staged launch reads what it was
+// built to read (a triangle's rows once per tile) and gives the same iterates bit for bit, but 170 B of LDS per thread leave
+// 8 of 32 waves per CU resident, and the launch it replaces runs at 5.9 TB/s of traffic BECAUSE it is at full occupancy:
+// torus100k 556 -> 500 it/s, sphere10k 4 960 -> 4 330, knot 10 350 -> 9 100.  Kept as an alternative, off by default.
+bool rhs_on_tiles(const Ctx *c) {
+    const TileDev &tl = c->tiles;
+    return c->rhs_tiles && tl.n_tiles > 0 && rhs_tiles_lds(c->d, tl) <= RHS_TILES_LDS_MAX;
+}
+
 int launch_rhs(Ctx *c, bool with_soc) {
     const int g = xcd_grid(c->d.n_vtiles);
     if (rhs_writes_modes(c) && time_modes_mfma_ok(c->d)) {      // (two time columns per lane measured here too: knot63 -1.5 %, torus65k_T127 +1.5 %: not kept)
         const int n_tiles = (c->d.V + TM_ROWS - 1) / TM_ROWS, n_rhs = xcd_grid(n_tiles);
         hipLaunchKernelGGL(k_rhs_modes_mfma, dim3(n_rhs + (with_soc ? g : 0)), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
                            c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, n_tiles, c->prm.scale_z, c->prm.const_d);
+    }
+    else if (rhs_writes_modes(c) && c->rhs_two && rhs_on_tiles(c)) {     // patch tiles, triangle rows staged in LDS (large meshes)
+        const TileDev &tl = c->tiles;
+        const int IC = time_modes_chunk(c->d), gt = xcd_grid(tl.n_tiles);
+        const size_t lds = rhs_tiles_lds(c->d, tl);
+        static bool raised = false;      // more than the default 64 KB of dynamic LDS needs the attribute (once per process)
+        if (!raised) {
+            DOTS_HIP(hipFuncSetAttribute((const void *)k_rhs_soc_tiles<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RHS_TILES_LDS_MAX));
+            DOTS_HIP(hipFuncSetAttribute((const void *)k_rhs_soc_tiles<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RHS_TILES_LDS_MAX));
+            raised = true;
+        }
+        if (with_soc) hipLaunchKernelGGL((k_rhs_soc_tiles<true>), dim3(gt), dim3(TILE2_NB), lds, c->stream, c->d, tl, c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0,
+                                         IC, c->prm.scale_z, c->prm.const_d);
+        else hipLaunchKernelGGL((k_rhs_soc_tiles<false>), dim3(gt), dim3(TILE2_NB), lds, c->stream, c->d, tl, c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0,
+                                IC, c->prm.scale_z, c->prm.const_d);
     }
     else if (rhs_writes_modes(c) && c->rhs_two && c->d.TP >= 4)      // two time columns per lane (16-byte accesses)
         hipLaunchKernelGGL(k_rhs_modes2, dim3(with_soc ? 2 * g : g), dim3(RHS_NB2), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,

@@ -69,6 +69,7 @@ class DeviceProblem:
         d.perm_tri = _ptr(p.perm_tri, C.c_int32)
         d.time_modes = _ptr(p.time_modes, C.c_double)
         d.time_eigs = _ptr(p.time_eigs, C.c_double)
+        d.patch_order = _ptr(getattr(p, "patch_order", None), C.c_int32)
         self.mode_slice = None
         self.node0, self.nl, self.ni = 0, p.n_time + 1, p.n_time
         self.slab = None

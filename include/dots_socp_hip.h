@@ -106,6 +106,11 @@ typedef struct dots_problem_desc {
     int32_t slab_count;
     int32_t slab_stride;
     int32_t reserved;
+    /* Optional (NULL: off): a sequence of all device vertices in which every aligned run of 16 * 2^k entries is a compact
+     * patch of the surface (dots_patch_order).  The right-hand-side / cone-projection launch then takes its vertex tiles
+     * from this sequence and stages the B, E rows of a tile's distinct triangles through LDS once, instead of gathering
+     * them per corner (solver_socp.py:909-921, :997-1017: the two SpMVs with incidence matrices).  Results do not change. */
+    const int32_t *patch_order;  /* [V] */
 } dots_problem_desc;
 
 /* Scalars the host control logic owns (solver_socp.py:97,318-321 and the kwargs of :25-41). */
@@ -392,6 +397,9 @@ int dots_front_setup(dots_ctx *ctx, const dots_front_desc *desc);
  * at position k), sep_ptr [n+1], child [n][2], parent [n], height [n].
  * dots_symbolic_build: boundary sets of the tree on the graph given in the numbering `order` refers to:
  * node_b [n], and per front row (separator rows first; dots_symbolic_front_rows of them) front_idx, pull0, pull1. */
+/* dots_patch_order: recursive coordinate bisection of the points `xyz` [V][3] (longest side of the bounding box, cut at a
+ * multiple of `unit`, leaves of <= unit points, siblings adjacent): order [V]. */
+int dots_patch_order(int32_t n_vertices, const double *xyz, int32_t unit, int32_t *order);
 typedef struct dots_tree dots_tree;
 typedef struct dots_symbolic dots_symbolic;
 int dots_tree_build(int32_t n_vertices, const int32_t *indptr, const int32_t *indices, const double *xyz, int32_t leaf, dots_tree **out);
