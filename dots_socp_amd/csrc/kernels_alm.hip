@@ -673,6 +673,8 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
 // the column of the node (idxM), so both nodes of a lane sit in one aligned 16-byte word of every row; the mesh constants of
 // (f, c) are loaded once for both.  Half the waves for the same bytes: these launches are latency-bound at full occupancy on
 // the small meshes (time ~ waves x chain / resident waves).  Element for element the arithmetic of k_q_lambda_mult_triangle.
+// (118 VGPRs = 4 waves per SIMD.  Forcing 5 / 6 with amdgpu_waves_per_eu spills 44 / 132 bytes per lane and loses: torus100k 571 -> 553 / 472 it/s,
+// knot 10 530 -> 9 750 / 7 980: profiles/studies/r03_steps23_forced_occupancy.txt)
 template <int ZMODE, bool QONLY = false>
 __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle2(Dev d, double sz, double tau, int nf8, double cd, double cr) {
     constexpr int SUB = TILE_ELEMS / (2 * BLOCK);     // two elements per thread: a workgroup takes half of a triangle tile
