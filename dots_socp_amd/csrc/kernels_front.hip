@@ -45,7 +45,10 @@
 #define DOTS_FRONT_UNROLL 1
 #endif
 #ifndef DOTS_FRONT_U2
-#define DOTS_FRONT_U2 1      // steps of the dot product in flight with two-mode lanes (A/B: -DDOTS_FRONT_U2=2)
+#define DOTS_FRONT_U2 1      // steps of the dot product in flight with two-mode lanes, forward fold kernel (A/B: -DDOTS_FRONT_U2=2)
+#endif
+#ifndef DOTS_FRONT_U2B
+#define DOTS_FRONT_U2B DOTS_FRONT_U2      // ... backward kernel
 #endif
 
 namespace dots {
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const
         for (int c = 0; c < VEC; ++c) acc[r].v[c] = 0.0;
         co[r] = (int64_t)(r < nc ? col0 + r : col0) << sh;
     }
-    constexpr int U = !DOTS_FRONT_UNROLL ? 1 : (VEC > 1 ? DOTS_FRONT_U2 : ((1 + RB) <= 4) ? 4 : 2);      // as in the forward sweep
+    constexpr int U = !DOTS_FRONT_UNROLL ? 1 : (VEC > 1 ? DOTS_FRONT_U2B : ((1 + RB) <= 4) ? 4 : 2);      // as in the forward sweep
     if (live) {
         // rows of the separators: y.  Column i of L^-1 is zero above the diagonal: start at the block's first column
 #pragma unroll
