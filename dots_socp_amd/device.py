@@ -181,10 +181,17 @@ class DeviceProblem:
 
     def step_times(self, wait=False, capacity=64):
         """Phase times of the timed enqueue-only steps that have finished (``wait``: of all of them), oldest first."""
-        buf = (_lib.StepStats * capacity)()
+        buf = getattr(self, "_times_buf", None)
+        if buf is None or len(buf) < capacity:
+            buf = self._times_buf = (_lib.StepStats * capacity)()
         n = C.c_int(0)
         _lib.check(self.lib.dots_step_times(self._h, buf, capacity, 1 if wait else 0, C.byref(n)), "dots_step_times")
-        return [buf[i] for i in range(n.value)]
+        out = []
+        for i in range(n.value):       # copies: the buffer is reused by the next call
+            st = _lib.StepStats()
+            C.pointer(st)[0] = buf[i]
+            out.append(st)
+        return out
 
     # ---- time slab (multi-GPU): stages of one iteration around the caller's exchanges (dots_slab_stage)
     def slab_elems(self, which):

@@ -414,7 +414,9 @@ class ShardedAlmSolver(AlmSolver):
             self.comm_seconds += t_comm
 
     def _collect_step_times(self, wait=False):
+        fresh = False
         while self._comm_events and (wait or self._comm_events[0][1][-1][1].query()):
+            fresh = True
             kind, events = self._comm_events.pop(0)
             if wait:
                 events[-1][1].synchronize()
@@ -422,6 +424,8 @@ class ShardedAlmSolver(AlmSolver):
             self.step_timers.add(kind, self.EXCHANGE_TAG, seconds)
             self.comm_seconds += seconds
         super()._collect_step_times(wait=wait)
+        if fresh and not wait:
+            self.step_timers.publish()
 
     # ---- scaling tools change mu / B-independent duals in place: the KKT halos of the neighbours are stale afterwards
     def adjust_penalty(self, factor):

@@ -115,8 +115,11 @@ class AlmSolver:
 
         self.run_history = RunningHistory(max_record_numbers=self.nit, kkt_labels=KKT_LABELS,
                                           kkt_short_labels=KKT_SHORT_LABELS, name="SOCP")
-        # per-step timers without a host wait in the loop (control.SampledStepTimers); DOTS_TIME_EVERY=1 times every iteration
-        self.step_timers = SampledStepTimers(self.run_history, first=4, every=int(env_choice("DOTS_TIME_EVERY", None, "8", integer=(1, 1 << 20))))
+        # per-step timers without a host wait in the loop (control.SampledStepTimers); DOTS_TIME_EVERY=1 times every iteration.
+        # The five events of a timed iteration cost ~30 us of stream time at knot (measured on the driver's 20-step window:
+        # 8 190 it/s without sampling, 7 870 with the first 4 + every 8th of a kind, profiles/tools/driver_window.py): the first 2
+        # of a kind and every 32nd are sampled (< 1 % of a 95-us iteration)
+        self.step_timers = SampledStepTimers(self.run_history, first=2, every=int(env_choice("DOTS_TIME_EVERY", None, "32", integer=(1, 1 << 20))))
         self.adjust_params = AdjustAdmmParam()
         self.is_org_kkt = False
         self.cg_total = self.cg_fail = 0
@@ -309,10 +312,13 @@ class AlmSolver:
 
     def _collect_step_times(self, wait=False):
         """Phase times of the timed iterations that have finished (at a read-back: all of them), into the history."""
+        fresh = False
         if self._timed_in_flight:
             for st in self.dev.step_times(wait=wait):
                 self._account(st, self._timed_in_flight.pop(0))
-        self.step_timers.publish()
+                fresh = True
+        if fresh or wait:       # (the estimate also scales with the iteration counts: brought up to date whenever it is asked for with wait=True)
+            self.step_timers.publish()
 
     def _time_is_up(self, reads_back=True):
         """``reads_back``: this iteration synchronises with the host anyway (the multi-GPU driver only shares the

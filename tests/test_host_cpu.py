@@ -363,9 +363,9 @@ def test_environment_switches_are_validated(monkeypatch):
         _lib.env_choice("DOTS_RHS_AHEAD", ("0", "1", "2"), "1")
     monkeypatch.setenv("DOTS_TIME_EVERY", "0")
     with pytest.raises(_lib.HipLibraryError, match="DOTS_TIME_EVERY"):
-        _lib.env_choice("DOTS_TIME_EVERY", None, "8", integer=(1, 1 << 20))
+        _lib.env_choice("DOTS_TIME_EVERY", None, "32", integer=(1, 1 << 20))
     monkeypatch.setenv("DOTS_TIME_EVERY", "16")
-    assert _lib.env_choice("DOTS_TIME_EVERY", None, "8", integer=(1, 1 << 20)) == "16"
+    assert _lib.env_choice("DOTS_TIME_EVERY", None, "32", integer=(1, 1 << 20)) == "16"
     # the switches the library reads itself are checked by dots_create / dots_tree_build (host code: no GPU needed for the latter)
     lib = _lib.load()
     import ctypes as C
