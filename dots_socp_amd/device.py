@@ -223,13 +223,14 @@ class DeviceProblem:
         mask = 0
         for i in conditions:
             mask |= 1 << int(i)
-        out = np.full(14, np.nan)
-        _lib.check(self.lib.dots_kkt(self._h, mask, _ptr(out, C.c_double)), "dots_kkt")
-        res = {}
-        for i in conditions:
-            second = float(out[2 * i + 1])
-            res[int(i)] = [float(out[2 * i]), None if i >= 4 else second]
-        return res
+        out = getattr(self, "_kkt_out", None)      # (the host's part of a read-back sits on the critical path: no allocations here)
+        if out is None:
+            out = self._kkt_out = np.empty(14)
+            self._kkt_out_p = _ptr(out, C.c_double)
+        out.fill(np.nan)
+        _lib.check(self.lib.dots_kkt(self._h, mask, self._kkt_out_p), "dots_kkt")
+        vals = out.tolist()
+        return {int(i): [vals[2 * i], None if i >= 4 else vals[2 * i + 1]] for i in conditions}
 
     @staticmethod
     def _mask(conditions):
