@@ -224,3 +224,49 @@ def test_two_components_and_empty_separators():
         dev.close()
     assert rel(out["direct"], out["direct_off"]) < 1e-10
     assert rel(out["direct"], out["pcg"]) < 1e-8
+
+
+@pytest.mark.parametrize("mesh,kw,T", [("sphere", dict(level=4), 31), ("torus", dict(nu=72, nv=40), 15), ("knot", dict(nu=240, nv=10), 7), ("sphere", dict(level=3), 63)])
+def test_forward_kernel_variants_agree(mesh, kw, T, monkeypatch):
+    """The forward sweep of a band runs in the fold kernel (k_front_fwd: a row split over the whole workgroup, folded through LDS)
+    or in the row kernel (k_front_fwd_rows: Q lane groups of a wavefront per row, the right-hand side staged once per workgroup),
+    chosen per band by a rule.  Forced onto EVERY band that fits them, with and without merged tree heights, all variants solve
+    the same systems: the solutions agree to rounding (the sums are formed in different orders), and a bad DOTS_FRONT_CFG is an error."""
+    import os
+
+    from dots_socp_amd import _lib
+
+    geom, _ = meshes.example(mesh, **kw)
+    pitch = max(8, 1 << int(np.ceil(np.log2(T + 1))))
+    groups = 64 // max(pitch // 2, 1)              # lane groups of a wavefront = the largest Q of the row kernel
+    out = {}
+    settings = [("rule", {}), ("fold", {"DOTS_FRONT_ROWS": "0"}), ("rows_everywhere", {"DOTS_FRONT_ROWS": "2"}),
+                ("unmerged_rule", {"DOTS_FRONT_BANDS": "off"}), ("unmerged_fold", {"DOTS_FRONT_BANDS": "off", "DOTS_FRONT_ROWS": "0"})]
+    for q in (1, 2, 4, 8):
+        if q <= groups:      # (the leaf band always fits the row kernel: its rows hold <= 16 columns)
+            settings.append((f"r{q}_leaves", {"DOTS_FRONT_BANDS": "off", "DOTS_FRONT_CFG": f"fwd:r{q}"}))
+    mass = None
+    for tag, env in settings:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dev = make(geom, T, 1e-3, "nd")
+        mass = dev.plan.mass_vert[np.argsort(dev.plan.perm_vert)] if mass is None else mass
+        dev.setup_frontal(eps=1e-3)
+        st = dev.run_phase("laplacian")
+        assert st.cg_not_converged == 0
+        out[tag] = dev.download("phi")
+        dev.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for tag, phi in out.items():
+        assert np.all(np.isfinite(phi)), tag
+        assert rel(phi, out["fold"]) < 1e-11, tag
+    monkeypatch.setenv("DOTS_FRONT_CFG", "fwd:r3")
+    dev = make(geom, T, 1e-3, "nd")
+    with pytest.raises(_lib.HipLibraryError, match="DOTS_FRONT_CFG"):
+        dev.setup_frontal(eps=1e-3)
+    dev.close()
+    monkeypatch.delenv("DOTS_FRONT_CFG")
+    monkeypatch.setenv("DOTS_FRONT_ROWS", "7")
+    with pytest.raises(_lib.HipLibraryError, match="DOTS_FRONT_ROWS"):
+        make(geom, T, 1e-3, "nd")
