@@ -30,7 +30,7 @@ EXPORTS = [
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
     "dots_slab_elems", "dots_slab_set_buffers", "dots_slab_stage", "dots_kkt_sums", "dots_kkt_sums_device", "dots_debug_counter", "dots_kkt_combine", "dots_objective_sums",
     "dots_objective_combine", "dots_front_launches", "dots_front_info", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_step_times", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
-    "dots_patch_order", "dots_symbolic_build", "dots_symbolic_front_rows", "dots_symbolic_copy", "dots_symbolic_free",
+    "dots_patch_order", "dots_assemble", "dots_assemble_nnz", "dots_assemble_copy", "dots_assemble_free", "dots_symbolic_build", "dots_symbolic_front_rows", "dots_symbolic_copy", "dots_symbolic_free",
 ]
 
 
@@ -246,6 +246,12 @@ def load():
     i64p = C.POINTER(C.c_int64)
     lib.dots_tree_build.argtypes = [C.c_int32, _i32p, _i32p, _f64p, C.c_int32, C.POINTER(vp)]
     lib.dots_patch_order.argtypes = [C.c_int32, _f64p, C.c_int32, _i32p]
+    lib.dots_assemble.argtypes = [C.c_int32, C.c_int32, _f64p, _i32p, C.POINTER(vp)]
+    lib.dots_assemble_nnz.argtypes = [vp]
+    lib.dots_assemble_nnz.restype = C.c_int64
+    lib.dots_assemble_copy.argtypes = [vp, _f64p, _f64p, _f64p, _i32p, _i32p, _i32p, _i32p, _f64p]
+    lib.dots_assemble_free.argtypes = [vp]
+    lib.dots_assemble_free.restype = None
     lib.dots_tree_nodes.argtypes = [vp]
     lib.dots_tree_nodes.restype = C.c_int64
     lib.dots_tree_copy.argtypes = [vp, i64p, i64p, _i32p, _i32p, _i32p]
@@ -262,7 +268,7 @@ def load():
     for n in EXPORTS:
         f = getattr(lib, n)
         if n not in ("dots_last_error", "dots_array_count", "dots_device_bytes", "dots_slab_elems", "dots_tree_nodes", "dots_tree_free", "dots_debug_counter",
-                     "dots_symbolic_front_rows", "dots_symbolic_free"):
+                     "dots_symbolic_front_rows", "dots_symbolic_free", "dots_assemble_nnz", "dots_assemble_free"):
             f.restype = C.c_int
     if lib.dots_abi_version() != ABI_VERSION:
         raise HipLibraryError("libdotsocp_hip.so ABI version mismatch; rebuild it")

@@ -13,6 +13,10 @@ struct dots_tree {
     std::vector<int64_t> order, sep_ptr;
     std::vector<int32_t> child, parent, height;
 };
+struct dots_mesh_ops {      // dots_assemble: the outputs of the reference's operator assembly as flat arrays
+    std::vector<double> area, hat, mass, val;
+    std::vector<int32_t> cptr, cidx, rowptr, col;
+};
 struct dots_symbolic {
     std::vector<int32_t> node_b, front_idx, pull0, pull1;
     int64_t update_rows = 0;
@@ -189,6 +193,94 @@ void patch_bisect(const double *xyz, int32_t *ids, int lo, int hi, int unit) {
 }  // namespace
 
 extern "C" {
+
+// Operator assembly (reference: utils/surface_pre_computations_socp.py:11-132, socp/solver_socp.py:102-113): triangle areas
+// (:25), hat-function gradients (:31-37), vertex masses (:112), the vertex -> corner lists in the reference's corner order
+// i = k F + f (:114-118) and K = G^T diag(area) G = minus the cotangent matrix (:68-84) as a sorted CSR.  The same formulas, in
+// the same order of operations, as dots_socp_amd/geometry.py (hat_gradients, corner_lists, stiffness_matrix: the reference
+// implementations the tests compare with); one pass over the triangles and one over the corner lists instead of numpy
+// temporaries and a sparse product: 0.01 s instead of 0.2 s at 10^5 vertices.
+int dots_assemble(int32_t V, int32_t F, const double *xyz, const int32_t *tri, dots_mesh_ops **out) {
+    if (V < 1 || F < 1 || !xyz || !tri || !out) { dots::set_error("assemble: bad argument"); return DOTS_ERR_ARGUMENT; }
+    for (int64_t i = 0; i < (int64_t)3 * F; ++i)
+        if (tri[i] < 0 || tri[i] >= V) { dots::set_error("assemble: triangle index out of range"); return DOTS_ERR_ARGUMENT; }
+    dots_mesh_ops *m = new dots_mesh_ops();
+    m->area.resize((size_t)F);
+    m->hat.resize((size_t)F * 9);
+    for (int f = 0; f < F; ++f) {
+        double p[3][3];
+        for (int k = 0; k < 3; ++k)
+            for (int c = 0; c < 3; ++c) p[k][c] = xyz[3 * (size_t)tri[3 * f + k] + c];
+        double u[3], w2[3];
+        for (int c = 0; c < 3; ++c) { u[c] = p[1][c] - p[0][c]; w2[c] = p[2][c] - p[1][c]; }
+        const double cx = u[1] * w2[2] - u[2] * w2[1], cy = u[2] * w2[0] - u[0] * w2[2], cz = u[0] * w2[1] - u[1] * w2[0];
+        m->area[(size_t)f] = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+        for (int k = 0; k < 3; ++k) {       // altitude from the opposite edge to corner k, over its squared length
+            const double *a = p[(k + 1) % 3], *b = p[(k + 2) % 3];
+            double e[3], w[3], alt[3];
+            for (int c = 0; c < 3; ++c) { e[c] = b[c] - a[c]; w[c] = p[k][c] - a[c]; }
+            const double we = w[0] * e[0] + w[1] * e[1] + w[2] * e[2], ee = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+            const double q = we / ee;
+            for (int c = 0; c < 3; ++c) alt[c] = w[c] - e[c] * q;
+            const double aa = alt[0] * alt[0] + alt[1] * alt[1] + alt[2] * alt[2];
+            for (int c = 0; c < 3; ++c) m->hat[((size_t)f * 3 + k) * 3 + c] = alt[c] / aa;
+        }
+    }
+    // corner lists, ordered by (k, f) within a vertex; masses in the same order of summation
+    m->cptr.assign((size_t)V + 1, 0);
+    for (int64_t i = 0; i < (int64_t)3 * F; ++i) m->cptr[(size_t)tri[i] + 1] += 1;
+    for (int v = 0; v < V; ++v) m->cptr[(size_t)v + 1] += m->cptr[(size_t)v];
+    m->cidx.resize((size_t)3 * F);
+    m->mass.assign((size_t)V, 0.0);
+    {
+        std::vector<int32_t> fill(m->cptr.begin(), m->cptr.end() - 1);
+        for (int k = 0; k < 3; ++k)
+            for (int f = 0; f < F; ++f) {
+                const int v = tri[3 * f + k];
+                m->cidx[(size_t)fill[(size_t)v]++] = f * 3 + k;
+                m->mass[(size_t)v] += m->area[(size_t)f];
+            }
+    }
+    for (int v = 0; v < V; ++v) m->mass[(size_t)v] /= 3.0;
+    // K, row by row: the contributions of a vertex's corners in list order, columns sorted
+    m->rowptr.assign((size_t)V + 1, 0);
+    std::vector<std::pair<int32_t, double>> row;
+    for (int v = 0; v < V; ++v) {
+        row.clear();
+        for (int j = m->cptr[(size_t)v]; j < m->cptr[(size_t)v + 1]; ++j) {
+            const int fk = m->cidx[(size_t)j], f = fk / 3;
+            const double *gk = &m->hat[(size_t)fk * 3];
+            for (int i = 0; i < 3; ++i) {
+                const double *gi = &m->hat[((size_t)f * 3 + i) * 3];
+                const double val = m->area[(size_t)f] * (gk[0] * gi[0] + gk[1] * gi[1] + gk[2] * gi[2]);
+                const int32_t u = tri[3 * f + i];
+                size_t at = 0;
+                while (at < row.size() && row[at].first != u) ++at;
+                if (at == row.size()) row.emplace_back(u, val);
+                else row[at].second += val;
+            }
+        }
+        std::sort(row.begin(), row.end(), [](const std::pair<int32_t, double> &x, const std::pair<int32_t, double> &y) { return x.first < y.first; });
+        for (const auto &e : row) { m->col.push_back(e.first); m->val.push_back(e.second); }
+        m->rowptr[(size_t)v + 1] = (int32_t)m->col.size();
+    }
+    *out = m;
+    return 0;
+}
+int64_t dots_assemble_nnz(const dots_mesh_ops *m) { return m ? (int64_t)m->col.size() : -1; }
+int dots_assemble_copy(const dots_mesh_ops *m, double *area, double *hat, double *mass, int32_t *cptr, int32_t *cidx, int32_t *rowptr, int32_t *col, double *val) {
+    if (!m || !area || !hat || !mass || !cptr || !cidx || !rowptr || !col || !val) { dots::set_error("assemble_copy: null argument"); return DOTS_ERR_ARGUMENT; }
+    std::copy(m->area.begin(), m->area.end(), area);
+    std::copy(m->hat.begin(), m->hat.end(), hat);
+    std::copy(m->mass.begin(), m->mass.end(), mass);
+    std::copy(m->cptr.begin(), m->cptr.end(), cptr);
+    std::copy(m->cidx.begin(), m->cidx.end(), cidx);
+    std::copy(m->rowptr.begin(), m->rowptr.end(), rowptr);
+    std::copy(m->col.begin(), m->col.end(), col);
+    std::copy(m->val.begin(), m->val.end(), val);
+    return 0;
+}
+void dots_assemble_free(dots_mesh_ops *m) { delete m; }
 
 int dots_patch_order(int32_t n_vertices, const double *xyz, int32_t unit, int32_t *order) {
     if (n_vertices < 1 || !xyz || unit < 1 || !order) { dots::set_error("patch_order: bad argument"); return DOTS_ERR_ARGUMENT; }

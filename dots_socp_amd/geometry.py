@@ -83,6 +83,33 @@ def stiffness_matrix(n_vertices, triangles, area, hat):
     return K
 
 
+def assemble_native(vertices, triangles):
+    """``hat_gradients`` + vertex masses + ``corner_lists`` + ``stiffness_matrix`` in one call of the library's host code
+    (``dots_assemble``: the same formulas in the same order of operations; the numpy functions of this module stay the
+    reference implementations the tests compare it with).  Returns (area, hat, mass, corner_ptr, corner_idx, K)."""
+    import ctypes as C
+
+    from . import _lib
+
+    v = np.ascontiguousarray(vertices, dtype=np.float64)
+    t = np.ascontiguousarray(triangles, dtype=np.int32)
+    V, F = v.shape[0], t.shape[0]
+    lib = _lib.load()
+    h = C.c_void_p()
+    f64, i32 = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    _lib.check(lib.dots_assemble(V, F, v.ctypes.data_as(f64), t.ctypes.data_as(i32), C.byref(h)), "dots_assemble")
+    try:
+        nnz = int(lib.dots_assemble_nnz(h))
+        area, hat, mass = np.empty(F), np.empty((F, 3, 3)), np.empty(V)
+        cptr, cidx = np.empty(V + 1, dtype=np.int32), np.empty(3 * F, dtype=np.int32)
+        rowptr, col, val = np.empty(V + 1, dtype=np.int32), np.empty(nnz, dtype=np.int32), np.empty(nnz)
+        _lib.check(lib.dots_assemble_copy(h, area.ctypes.data_as(f64), hat.ctypes.data_as(f64), mass.ctypes.data_as(f64), cptr.ctypes.data_as(i32),
+                                          cidx.ctypes.data_as(i32), rowptr.ctypes.data_as(i32), col.ctypes.data_as(i32), val.ctypes.data_as(f64)), "dots_assemble_copy")
+    finally:
+        lib.dots_assemble_free(h)
+    return area, hat, mass, cptr, cidx, sp.csr_matrix((val, col, rowptr), shape=(V, V))
+
+
 def corner_lists(n_vertices, triangles):
     """vertex -> corners CSR.  Corners of a vertex are ordered by (k, f), i.e. by the reference's
     corner index i = k*F + f (surface_pre_computations_socp.py:114-118)."""
@@ -195,17 +222,11 @@ def build_plan(n_time, geometry, reorder=True, nd_leaf=16) -> DevicePlan:
         triangles = inv[triangles[perm_f]]
         mu0, mu1 = mu0[perm_v], mu1[perm_v]
 
-    area, hat = hat_gradients(vertices, triangles)
+    area, hat, mass, cptr, cidx, K = assemble_native(vertices, triangles)
     if not np.all(area > 0):
         raise ValueError("degenerate triangle (zero area)")
-    mass = np.zeros(V)
-    for k in range(3):
-        np.add.at(mass, triangles[:, k], area)
-    mass /= 3.0
     if not np.all(mass > 0):
         raise ValueError("isolated vertex (no incident triangle)")
-    K = stiffness_matrix(V, triangles, area, hat)
-    cptr, cidx = corner_lists(V, triangles)
     Q, sigma = time_modes(n_time)
     c = np.ascontiguousarray
     return DevicePlan(

@@ -397,6 +397,15 @@ int dots_front_setup(dots_ctx *ctx, const dots_front_desc *desc);
  * at position k), sep_ptr [n+1], child [n][2], parent [n], height [n].
  * dots_symbolic_build: boundary sets of the tree on the graph given in the numbering `order` refers to:
  * node_b [n], and per front row (separator rows first; dots_symbolic_front_rows of them) front_idx, pull0, pull1. */
+/* dots_assemble: the operator assembly of utils/surface_pre_computations_socp.py:11-132 / solver_socp.py:102-113 for the mesh
+ * (xyz [V][3], tri [F][3]) on the host: area [F], hat gradients [F][3][3], vertex masses [V], vertex -> corner lists
+ * (cptr [V+1], cidx [3F], corners of a vertex ordered by the reference's corner index k F + f) and K = G^T diag(area) G as a
+ * sorted CSR (rowptr [V+1], col / val [dots_assemble_nnz]): the arrays dots_problem_desc takes. */
+typedef struct dots_mesh_ops dots_mesh_ops;
+int dots_assemble(int32_t n_vertices, int32_t n_triangles, const double *xyz, const int32_t *tri, dots_mesh_ops **out);
+int64_t dots_assemble_nnz(const dots_mesh_ops *ops);
+int dots_assemble_copy(const dots_mesh_ops *ops, double *area, double *hat, double *mass, int32_t *cptr, int32_t *cidx, int32_t *rowptr, int32_t *col, double *val);
+void dots_assemble_free(dots_mesh_ops *ops);
 /* dots_patch_order: recursive coordinate bisection of the points `xyz` [V][3] (longest side of the bounding box, cut at a
  * multiple of `unit`, leaves of <= unit points, siblings adjacent): order [V]. */
 int dots_patch_order(int32_t n_vertices, const double *xyz, int32_t unit, int32_t *order);

@@ -448,3 +448,29 @@ def test_bench_launches_its_own_ranks(monkeypatch, capsys):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 0
+
+
+def test_native_assembly_matches_the_numpy_reference():
+    """dots_assemble (host code of the library) against the numpy functions of geometry.py, which the oracle tests pin to the
+    reference's assembly (surface_pre_computations_socp.py:11-132): areas, hat gradients, masses and corner lists identical,
+    K equal to rounding (its entries are summed in a different order) on the same sorted pattern."""
+    from dots_socp_amd import geometry, meshes
+
+    for v, t in (meshes.icosphere(3), meshes.torus(40, 24), meshes.plane(12)[:2], meshes.torus_knot_tube(nu=96, nv=8)):
+        t = np.asarray(t)
+        area, hat, mass, cptr, cidx, K = geometry.assemble_native(v, t)
+        area0, hat0 = geometry.hat_gradients(v, t)
+        assert np.allclose(area, area0, rtol=1e-15, atol=0) and np.allclose(hat, hat0, rtol=1e-13, atol=1e-15)
+        mass0 = np.zeros(v.shape[0])
+        for k in range(3):
+            np.add.at(mass0, t[:, k], area0)
+        assert np.allclose(mass, mass0 / 3.0, rtol=1e-15, atol=0)
+        cptr0, cidx0 = geometry.corner_lists(v.shape[0], t)
+        assert np.array_equal(cptr, cptr0) and np.array_equal(cidx, cidx0)
+        K0 = geometry.stiffness_matrix(v.shape[0], t, area0, hat0)
+        assert K.has_sorted_indices and K.shape == K0.shape
+        d = abs(K - K0)
+        assert d.max() <= 1e-13 * abs(K0).max()
+        assert abs(np.asarray(K.sum(axis=1))).max() <= 1e-12 * abs(K0).max()          # rows of the cotangent matrix sum to zero
+    with pytest.raises(Exception, match="out of range"):
+        geometry.assemble_native(v, np.array([[0, 1, v.shape[0]]]))
