@@ -203,7 +203,7 @@ static int build(Ctx *c, const dots_problem_desc *p) {
         TileDev &tl = c->tiles;
         tl.VTL = 512 / tpg;
         tl.n_tiles = (V + tl.VTL - 1) / tl.VTL;
-        std::vector<int> tv((size_t)tl.n_tiles * tl.VTL, -1), tptr((size_t)tl.n_tiles + 1, 0), ttri, cloc((size_t)nC, 0), stamp((size_t)F, -1), pos((size_t)F, 0);
+        std::vector<int> tv((size_t)std::max(tl.n_tiles * tl.VTL, d.n_vtiles * d.VT), -1), tptr((size_t)tl.n_tiles + 1, 0), ttri, cloc((size_t)nC, 0), stamp((size_t)F, -1), pos((size_t)F, 0);
         std::vector<char> seen((size_t)V, 0);
         for (int i = 0; i < V; ++i) {
             const int v = p->patch_order[i];
@@ -493,7 +493,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
         ok &= env_int("DOTS_QL_TWO", 0, 1, &c->ql_two);
         ok &= env_int("DOTS_KKT_TWO", 0, 1, &c->kkt_two);
         ok &= env_int("DOTS_RHS_TWO", 0, 1, &c->rhs_two);
-        ok &= env_int("DOTS_RHS_TILES", 0, 1, &c->rhs_tiles);
+        ok &= env_int("DOTS_RHS_TILES", 0, 2, &c->rhs_tiles);
         ok &= env_int("DOTS_SPIN_FETCH", 0, 1, &c->spin_fetch);
         ok &= env_int("DOTS_FRONT_VEC2", 0, 3, &c->front_vec2);      // 0 never, 1 / 2 wherever the pitch allows (default), 3 only where bandwidth-bound
         ok &= env_int("DOTS_FRONT_RB", 1, 4, &c->front_rb_max);

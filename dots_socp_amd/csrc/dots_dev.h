@@ -289,7 +289,7 @@ struct Ctx {
     int kkt_two = 1;              // KKT sums with two nodes per lane (one GPU; DOTS_KKT_TWO=0: one)
     int ql_two = 1;               // steps 2+3 with two nodes per lane (DOTS_QL_TWO=0: one, for A/B measurements)
     int rhs_two = 1;              // right-hand side + projection with two time columns per lane (DOTS_RHS_TWO=0: one)
-    int rhs_tiles = 0;            // ... on patch tiles with the triangle rows staged in LDS (DOTS_RHS_TILES=1; measured slower: off by default)
+    int rhs_tiles = 0;            // DOTS_RHS_TILES: 1 patch tiles with the triangle rows staged in LDS (measured slower), 2 the plain launch on patch tiles (no difference); default 0
     TileDev tiles{};
     // DOTS_STEP_TIMED: phase events of enqueue-only steps, collected later by dots_step_times (no host wait in the loop)
     static constexpr int TIME_SLOTS = 64;

@@ -389,13 +389,15 @@ __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r,
 
 // k_rhs_modes with two time columns per lane (one GPU, direct solver): 512 threads per tile.
 constexpr int RHS_NB2 = RHS_NB / 2;
-__global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double eps, double *__restrict__ bhat, int IC, int n_rhs, double sz, double cd) {
+__global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double eps, double *__restrict__ bhat, int IC, int n_rhs, double sz, double cd,
+                                                        const int *__restrict__ tile_vertex) {
+    // tile_vertex (or null): the tiles' vertices taken from dots_problem_desc.patch_order instead of from the numbering
     const int e = 2 * threadIdx.x, vl = e >> d.tp_shift, t = e & (d.TP - 1);
     if ((int)blockIdx.x >= n_rhs) {
         const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
         if (st >= d.n_vtiles) return;
-        const int v = st * d.VT + vl;
-        if (v < d.V && t < d.ni) soc_element2<false>(d, v, t, sz, cd);
+        const int v = tile_vertex ? tile_vertex[st * d.VT + vl] : (st * d.VT + vl < d.V ? st * d.VT + vl : -1);
+        if (v >= 0 && t < d.ni) soc_element2<false>(d, v, t, sz, cd);
         return;
     }
     extern __shared__ double tm_lds[];
@@ -405,15 +407,17 @@ __global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double 
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
     if (tile >= d.n_vtiles) return;
     const int v0 = tile * d.VT;
+    const int *__restrict__ tv = tile_vertex ? tile_vertex + v0 : nullptr;
     stage_q_chunk<true, RHS_NB2>(d, d.Q, Qs, 0, min(IC, n));      // in flight while the corner walks run
     for (int ee = e; ee < TILE_ELEMS; ee += 2 * RHS_NB2) {       // (one pass: TILE_ELEMS = 2 * RHS_NB2)
         const int vv = ee >> d.tp_shift, tt = ee & (TP - 1);
+        const int v = tv ? tv[vv] : (v0 + vv < d.V ? v0 + vv : -1);
         double b[2] = {0.0, 0.0};
-        if (v0 + vv < d.V && tt < n) rhs_value2<false>(d, v0 + vv, tt, r, eps, b);
+        if (v >= 0 && tt < n) rhs_value2<false>(d, v, tt, r, eps, b);
         xs[vv * TPp + tt] = b[0];
         xs[vv * TPp + tt + 1] = tt + 1 < n ? b[1] : 0.0;
     }
-    modes_from_tile<true, RHS_NB2>(d, d.Q, xs, Qs, IC, v0, bhat, -1, 0, 1 << 30, true);
+    modes_from_tile<true, RHS_NB2>(d, d.Q, xs, Qs, IC, v0, bhat, -1, 0, 1 << 30, true, tv);
 }
 
 // The right-hand side + projection launch on PATCH tiles (dots_problem_desc.patch_order): a workgroup of 256 threads takes
@@ -508,7 +512,7 @@ static size_t rhs_tiles_lds(const Dev &d, const TileDev &tl) {
 // torus100k 556 -> 500 it/s, sphere10k 4 960 -> 4 330, knot 10 350 -> 9 100.  Kept as an alternative, off by default.
 bool rhs_on_tiles(const Ctx *c) {
     const TileDev &tl = c->tiles;
-    return c->rhs_tiles && tl.n_tiles > 0 && rhs_tiles_lds(c->d, tl) <= RHS_TILES_LDS_MAX;
+    return c->rhs_tiles == 1 && tl.n_tiles > 0 && rhs_tiles_lds(c->d, tl) <= RHS_TILES_LDS_MAX;
 }
 
 int launch_rhs(Ctx *c, bool with_soc) {
@@ -535,7 +539,8 @@ int launch_rhs(Ctx *c, bool with_soc) {
     }
     else if (rhs_writes_modes(c) && c->rhs_two && c->d.TP >= 4)      // two time columns per lane (16-byte accesses)
         hipLaunchKernelGGL(k_rhs_modes2, dim3(with_soc ? 2 * g : g), dim3(RHS_NB2), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
-                           c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d);
+                           c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d,
+                           (c->rhs_tiles == 2 && c->tiles.n_tiles > 0) ? c->tiles.vertex : (const int *)nullptr);
     else if (rhs_writes_modes(c))
         hipLaunchKernelGGL(k_rhs_modes, dim3(with_soc ? 2 * g : g), dim3(RHS_NB), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
                            c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d);

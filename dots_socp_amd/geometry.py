@@ -238,5 +238,5 @@ def build_plan(n_time, geometry, reorder=True, nd_leaf=16) -> DevicePlan:
         perm_vert=None if perm_v is None else c(perm_v.astype(np.int32)),
         perm_tri=None if perm_f is None else c(perm_f.astype(np.int32)),
         time_modes=c(Q), time_eigs=c(sigma), area_mesh=float(area.sum()), vertices=c(vertices), dissection=diss,
-        patch_order=c(patch_order(vertices)) if env_choice("DOTS_RHS_TILES", ("0", "1"), "0") == "1" else None,
+        patch_order=c(patch_order(vertices)) if env_choice("DOTS_RHS_TILES", ("0", "1", "2"), "0") != "0" else None,
     )

@@ -337,7 +337,7 @@ def test_patch_tiles_are_bit_identical(fname):
     same corner lists with the same arithmetic: the same run, bit for bit (T + 1 = 16, 32 and 8: three tile shapes)."""
     g = golden(fname)
     runs = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         os.environ["DOTS_RHS_TILES"] = mode
         try:
             runs[mode] = run_hip(g, lap_solver="modal_direct")
@@ -348,3 +348,4 @@ def test_patch_tiles_are_bit_identical(fname):
     assert np.array_equal(h0.kkt_errors, h2.kkt_errors, equal_nan=True)
     for k in ("phi", "mu", "E", "A", "B", "z_fst", "z_end", "beta_mid"):
         assert np.array_equal(s0[k], s2[k]), k
+        assert np.array_equal(s0[k], runs["2"][0][k]), k        # mode 2: the plain launch, its tiles cut from the patch order
