@@ -8,4 +8,4 @@ drives hand-written HIP kernels for gfx950 through the C ABI declared in
 ``include/dots_socp_hip.h`` (``csrc/`` builds ``libdotsocp_hip.so``).
 There is no CPU fallback: without the HIP library every solver call raises.
 """
-__version__ = "0.1.0"
+__version__ = "0.3.0"
