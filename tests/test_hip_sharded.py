@@ -330,8 +330,9 @@ def _rccl_worker(rank, world, port, fname, out_dir):
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(0)
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    dev = rank % torch.cuda.device_count()          # one rank per GPU (a single rank on a one-GPU box)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
     try:
         from dots_socp_amd.distributed import TorchComm, solver_socp_sharded
 
@@ -339,7 +340,7 @@ def _rccl_worker(rank, world, port, fname, out_dir):
         kw = {k[3:]: (g[k].tolist() if g[k].ndim else g[k].item()) for k in g.files if k.startswith("kw_")}
         comm = TorchComm()
         assert comm.backend == "nccl" and comm.size == world
-        sol, hist = solver_socp_sharded(int(g["n_time"]), geom_of(g), comm=comm, device=0, lap_solver="modal_direct", **kw)
+        sol, hist = solver_socp_sharded(int(g["n_time"]), geom_of(g), comm=comm, device=dev, lap_solver="modal_direct", **kw)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), kkt=hist.kkt_errors, it=hist.kkt_iteration,
                  cost=hist.history["Transportation cost"], mu=sol["mu"], calls=np.array([comm.calls[k] for k in sorted(comm.calls)]))
     finally:
@@ -473,3 +474,39 @@ def test_kkt_sums_reach_the_all_reduce_without_a_host_round_trip():
         assert moved["gather_array"] == 8 * stride * (8 * V + 42 * F)                # 12 arrays, 1 / R of each (padded to the slab)
         assert moved["all_reduce"] == 8 * (24 + 3)                                   # the final KKT sums + the objective's three
     assert np.array_equal(out[0][4], out[1][4])
+
+
+def _gpus():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("fname,world", [("run_ico2_T15_cong_tol1e-3.npz", 2), ("run_torus_T7_tol1e-4.npz", 4), ("run_ico2_T15_palm_tol1e-3.npz", 2)])
+def test_rccl_backend_several_ranks(fname, world, tmp_path):
+    """The FIRST thing to run on a node with several GPUs: the recorded runs of the reference through the sharded driver
+    over RCCL with one rank per GPU -- the neighbour exchanges over xGMI (batch_isend_irecv), the two all-gathers, the all-reduced
+    KKT sums, enqueue-only iterations ordered against RCCL's streams -- with the same assertions as the thread and gloo tests:
+    every rank stops at the reference's iteration with its KKT values and cost, all ranks hold the same solution bit for bit.
+    Skipped on boxes with fewer GPUs than ranks (RCCL refuses two ranks on one device)."""
+    if _gpus() < world:
+        pytest.skip(f"needs {world} GPUs (one rank per GPU over RCCL); this box has {_gpus()}")
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_worker, args=(world, port, fname, str(tmp_path)), nprocs=world, join=True)
+    g = golden(fname)
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    want = g["hist_kkt_errors"]
+    for r in ranks:
+        assert int(r["it"][-1]) == int(g["last_iteration"])
+        assert np.array_equal(np.isnan(r["kkt"]), np.isnan(want))
+        m = ~np.isnan(want)
+        assert np.allclose(r["kkt"][m], want[m], rtol=1e-6, atol=1e-13)
+        assert np.allclose(r["cost"], g["hist_Transportation_cost"], rtol=1e-6, equal_nan=True)
+        assert np.max(np.abs(r["mu"] - g["sol_mu"])) < 1e-5 * np.max(np.abs(g["sol_mu"]))
+        assert np.array_equal(r["mu"], ranks[0]["mu"])
