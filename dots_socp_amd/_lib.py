@@ -10,7 +10,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libdotsocp_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ARRAY_IDS = {
     "phi": 0, "A": 1, "B": 2, "lambda_c": 3, "z_fst": 4, "z_mid": 5, "z_end": 6,
@@ -18,7 +18,7 @@ ARRAY_IDS = {
 }
 LAP_SOLVERS = {"spacetime_pcg": 0, "modal_pcg": 1}
 PHASES = {"laplacian": 0, "soc_projection": 1, "q_lambda_mult": 2, "q_lambda": 3}
-STEP_SKIP_Z_MID, STEP_PALM, STEP_RHS_AHEAD, STEP_TIMED = 1, 2, 4, 8
+STEP_SKIP_Z_MID, STEP_PALM, STEP_RHS_AHEAD, STEP_TIMED, STEP_CARRY = 1, 2, 4, 8, 16
 OPERATORS = {
     "grad_time": 0, "div_time": 1, "grad_space": 2, "div_space": 3, "decouple": 4,
     "decouple_adjoint": 5, "time_avg_adjoint": 6, "laplacian_apply": 7,
@@ -121,7 +121,7 @@ SLAB_SIZES = {"vertex_halo": 0, "b_chunk": 1, "x_chunk": 2, "triangle_halo": 3}
 # not in this list, or a value outside a switch's domain, is an error: a typo must not silently select the default.
 KNOWN_ENV = {
     # read by the library (csrc/dots_api.hip: env_int)
-    "DOTS_CG_STAGE_LDS", "DOTS_MG_TAIL_ROWS", "DOTS_SOC_WITH_RHS", "DOTS_QL_TWO", "DOTS_KKT_TWO", "DOTS_RHS_TWO", "DOTS_RHS_TILES", "DOTS_SPIN_FETCH",
+    "DOTS_CG_STAGE_LDS", "DOTS_MG_TAIL_ROWS", "DOTS_SOC_WITH_RHS", "DOTS_QL_TWO", "DOTS_KKT_TWO", "DOTS_RHS_TWO", "DOTS_RHS_TILES", "DOTS_CARRY", "DOTS_SPIN_FETCH",
     "DOTS_FRONT_VEC2", "DOTS_FRONT_RB", "DOTS_FRONT_ROWS", "DOTS_FRONT_XCD", "DOTS_FRONT_TUNE", "DOTS_FRONT_CFG", "DOTS_MAIL_TEST_DROP",
     "DOTS_MAIL_SPINS", "DOTS_ND_PCA_MIN",
     # read by the host side

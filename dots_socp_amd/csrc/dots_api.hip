@@ -170,6 +170,11 @@ static int build(Ctx *c, const dots_problem_desc *p) {
         for (int j = 0; j < nC; ++j) fkD[(size_t)p->corner_idx[j]] = cD[(size_t)j];
         UP(fk_D, fkD.data(), nC);
     }
+    {
+        std::vector<int> cpos((size_t)nC);
+        for (int j = 0; j < nC; ++j) cpos[(size_t)p->corner_idx[j]] = j;
+        UP(cpos, cpos.data(), nC);
+    }
     UP(c_gA, cgA.data(), nC * 3);
     UP(c_area, cArea.data(), nC);
     UP(rowptr, p->lap_rowptr, V + 1);
@@ -313,7 +318,7 @@ static int check(dots_ctx *ctx, bool reads_only = false) {
     if (!ctx) { set_error("null context"); return DOTS_ERR_ARGUMENT; }
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
-    if (!reads_only) ctx->rhs_ahead = ctx->rhs_ahead_armed = 0;
+    if (!reads_only) ctx->rhs_ahead = ctx->rhs_ahead_armed = ctx->carry_valid = 0;      // (the carried gathers belong to the state steps 2+3 left)
     return 0;
 }
 
@@ -321,6 +326,7 @@ static int check(dots_ctx *ctx, bool reads_only = false) {
 static int palm_step0(Ctx *c) {
     if (!c->step_palm) return 0;
     if (c->zmid_stale) { set_error("step: DOTS_STEP_PALM needs z_mid of the previous iteration in memory"); return DOTS_ERR_STATE; }
+    c->carry_valid = 0;      // step 0 moves A, B and lambda_c
     return launch_q_lambda_only(c);
 }
 
@@ -494,6 +500,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
         ok &= env_int("DOTS_KKT_TWO", 0, 1, &c->kkt_two);
         ok &= env_int("DOTS_RHS_TWO", 0, 1, &c->rhs_two);
         ok &= env_int("DOTS_RHS_TILES", 0, 2, &c->rhs_tiles);
+        ok &= env_int("DOTS_CARRY", 0, 1, &c->carry_arrays);       // 0: never allocate the carried gathers (DOTS_STEP_CARRY is then ignored)
         ok &= env_int("DOTS_SPIN_FETCH", 0, 1, &c->spin_fetch);
         ok &= env_int("DOTS_FRONT_VEC2", 0, 3, &c->front_vec2);      // 0 never, 1 / 2 wherever the pitch allows (default), 3 only where bandwidth-bound
         ok &= env_int("DOTS_FRONT_RB", 1, 4, &c->front_rb_max);
@@ -692,13 +699,14 @@ int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
 int dots_step_flags(dots_ctx *c, uint32_t flags) {
     int rc = check(c, true);
     if (rc) return rc;
-    if (flags & ~(uint32_t)(DOTS_STEP_SKIP_Z_MID | DOTS_STEP_PALM | DOTS_STEP_RHS_AHEAD | DOTS_STEP_TIMED)) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
+    if (flags & ~(uint32_t)(DOTS_STEP_SKIP_Z_MID | DOTS_STEP_PALM | DOTS_STEP_RHS_AHEAD | DOTS_STEP_TIMED | DOTS_STEP_CARRY)) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
     if ((flags & DOTS_STEP_RHS_AHEAD) && (flags & DOTS_STEP_PALM)) { set_error("step_flags: DOTS_STEP_RHS_AHEAD cannot be combined with DOTS_STEP_PALM (its step 0 changes what the right-hand side reads)"); return DOTS_ERR_ARGUMENT; }
     c->rhs_ahead_armed = ((flags & DOTS_STEP_RHS_AHEAD) && rhs_writes_modes(c)) ? 1 : 0;      // (a hint: ignored without the direct solver / on a time slab)
     if ((flags & DOTS_STEP_SKIP_Z_MID) && (flags & DOTS_STEP_PALM)) { set_error("step_flags: DOTS_STEP_PALM reads z_mid, it cannot be combined with DOTS_STEP_SKIP_Z_MID"); return DOTS_ERR_ARGUMENT; }
     c->step_skip_zmid = (flags & DOTS_STEP_SKIP_Z_MID) ? 1 : 0;
     c->step_palm = (flags & DOTS_STEP_PALM) ? 1 : 0;
     c->step_timed = (flags & DOTS_STEP_TIMED) ? 1 : 0;
+    c->step_carry = ((flags & DOTS_STEP_CARRY) && !(flags & DOTS_STEP_PALM)) ? 1 : 0;      // (a hint, like DOTS_STEP_RHS_AHEAD)
     return 0;
 }
 
@@ -993,7 +1001,21 @@ int dots_front_setup(dots_ctx *c, const dots_front_desc *desc) {
     int rc = check(c);
     if (rc) return rc;
     if (c->lap_solver != DOTS_LAP_MODAL_PCG) { set_error("the direct solve needs the modal solver"); return DOTS_ERR_ARGUMENT; }
-    return front_setup(c, desc);
+    c->d.cn_sq = c->d.cn_g = nullptr;
+    if ((rc = front_setup(c, desc))) return rc;
+    // DOTS_STEP_CARRY: the per-corner gathers steps 2+3 leave for the next right-hand side / projection (one GPU, pitch <= 128);
+    // they belong to the direct solver's iteration and are released with the factor
+    if (c->shard_stride == 0 && c->d.TP <= 128 && c->carry_arrays) {
+        const int64_t rows = (int64_t)3 * c->d.F;
+        const double *sq = nullptr, *g = nullptr;
+        if ((rc = front_upload<double>(c, &sq, nullptr, (2 * rows) << c->d.tp_shift)) || (rc = front_upload<double>(c, &g, nullptr, rows << c->d.tp_shift))) {
+            front_release(c);
+            return rc;
+        }
+        c->d.cn_sq = const_cast<double *>(sq);
+        c->d.cn_g = const_cast<double *>(g);
+    }
+    return 0;
 }
 
 int dots_front_enable(dots_ctx *c, int on) {

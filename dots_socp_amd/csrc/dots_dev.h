@@ -77,6 +77,11 @@ struct Dev {
     // state
     double *phi, *A, *B, *lam, *zf, *zm, *ze, *mu, *E, *bf, *bm, *be;
     double *lamc;            // [V][TP] cone multiplier of the last projection (z_mid = lamc/D * pre-image, rebuilt in steps 2+3)
+    // DOTS_STEP_CARRY (one GPU, direct solver, pitch <= 128; null otherwise): what the right-hand side and the cone projection of the
+    // NEXT iteration gather per corner, stored by steps 2+3 in corner-LIST order (row j = position in cidx; cpos: f*3+k -> j)
+    double *cn_sq;           // [3F][2][TP] halves s = 0, 1 of sum_xyz (D (sz/sqrt3 B - beta_mid))^2, column = interval
+    double *cn_g;            // [3F][TP]    sum_xyz area * hat * (B - E), column = node
+    const int *cpos;         // [3F]
     // halos of a time slab (device arrays, written by dots_slab_unpack / the inverse transform; see SlabHalo in dots_api.hip)
     const double *X_lo;      // [V]  (A + lambda_c - mu) of interval t0 - 1           (right-hand side at node t0)
     const double *lamc_lo;   // [V]  cone multiplier of interval t0 - 1                (steps 2+3 at node t0)
@@ -289,6 +294,7 @@ struct Ctx {
     int kkt_two = 1;              // KKT sums with two nodes per lane (one GPU; DOTS_KKT_TWO=0: one)
     int ql_two = 1;               // steps 2+3 with two nodes per lane (DOTS_QL_TWO=0: one, for A/B measurements)
     int rhs_two = 1;              // right-hand side + projection with two time columns per lane (DOTS_RHS_TWO=0: one)
+    int carry_arrays = 1;         // DOTS_CARRY=0: no carried gathers (A/B measurements; dots_front_setup then allocates nothing for them)
     int rhs_tiles = 0;            // DOTS_RHS_TILES: 1 patch tiles with the triangle rows staged in LDS (measured slower), 2 the plain launch on patch tiles (no difference); default 0
     TileDev tiles{};
     // DOTS_STEP_TIMED: phase events of enqueue-only steps, collected later by dots_step_times (no host wait in the loop)
@@ -299,6 +305,8 @@ struct Ctx {
     int step_timed = 0;           // dots_step_flags
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
     int step_palm = 0;            // dots_step_flags: every iteration opens with the (q, lambda_c) closed form (is_palm = True)
+    int step_carry = 0;           // dots_step_flags: steps 2+3 also store the next iteration's per-corner gathers (cn_sq, cn_g)
+    int carry_valid = 0;          // ... and they belong to the current iterate (cleared by every call that changes state or parameters)
     int zmid_stale = 0;           // z_mid does not belong to the current iterate
     FrontDev front{};             // multifrontal factor (n_nodes == 0: none)
     int use_front = 0;
@@ -369,6 +377,10 @@ inline bool rhs_writes_modes(const Ctx *c) {
 }
 
 inline bool soc_takes_inverse(const Ctx *c) { return rhs_writes_modes(c) && !time_modes_mfma_ok(c->d); }
+// steps 2+3 can form the next iteration's per-corner gathers (k_q_lambda_mult_carry: whole triangles per 192-lane workgroup)
+inline bool carry_possible(const Ctx *c) {
+    return c->d.cn_sq && c->ql_two && !c->d.slab && c->d.TP >= 4 && c->d.TP <= 128 && rhs_writes_modes(c);
+}
 // ... or the projection itself rides in the right-hand-side launch (enqueue-only iterations; TILE_ELEMS threads per tile)
 inline bool rhs_takes_soc(const Ctx *c) { return c->soc_with_rhs && rhs_writes_modes(c); }
 

@@ -25,46 +25,61 @@ namespace dots {
 // B and beta_mid (soc_half_of_first_node) and this one reads it from the halo -- bit for bit the same sum.
 // two consecutive time columns of a row (16-byte aligned: even column, pitch a power of two)
 
+// A corner's share of a sum over xyz is formed FIRST, as (x + y) + z, and the shares are then added in corner-list order: the
+// kernels that gather these terms from memory and the steps-2+3 kernel that forms them from its registers for the next
+// iteration (DOTS_STEP_CARRY: cn_sq, cn_g below) then produce the same sums bit for bit (-ffp-contract=off: no fused multiply-adds).
+__device__ __forceinline__ double sum3(double x, double y, double z) { return (x + y) + z; }
+// one pre-image entry of the cone's middle block squared: (D (sB B - beta_mid))^2, sBB = sB * B already rounded
+__device__ __forceinline__ double soc_w2(double D, double sBB, double bm) {
+    const double w = D * (sBB - bm);
+    return w * w;
+}
+
 __device__ __forceinline__ double soc_half(const Dev &d, int v, int t, int s, double sB) {
     double acc = 0.0;
     for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
         const int fk = d.cidx[j];
         const int f = fk / 3;
         const double D = d.c_D[j];
+        double q[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double w = D * (sB * d.B[idxF(d, f, c, t + s)] - d.bm[idxM(d, fk, s, c, t)]);
-            acc += w * w;
-        }
+        for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * d.B[idxF(d, f, c, t + s)], d.bm[idxM(d, fk, s, c, t)]);
+        acc += sum3(q[0], q[1], q[2]);
     }
     return acc;
 }
 
-template <bool ONLY_MULTIPLIER>
+// CARRIED: the corners' shares of both halves were stored by the last steps-2+3 launch (cn_sq[j][s][interval], in corner-LIST
+// order: a vertex's rows are contiguous): two loads per corner, no index chain, neither B nor beta_mid is touched.
+template <bool ONLY_MULTIPLIER, bool CARRIED = false>
 __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double sz, double cd) {
     const double sB = sz * INV_SQRT3;
     const int iv = idxV(d, v, t);
     const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
     const bool own1 = t + 1 < d.nl;      // node t + 1 is held here (always on one GPU)
     double acc0 = 0.0, acc1 = 0.0;
-    for (int j = j0; j < j1; ++j) {
-        const int fk = d.cidx[j];
-        const int f = fk / 3;
-        const double D = d.c_D[j];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double w = D * (sB * d.B[idxF(d, f, c, t)] - d.bm[idxM(d, fk, 0, c, t)]);
-            acc0 += w * w;
+    if (CARRIED) {
+        for (int j = j0; j < j1; ++j) {
+            acc0 += d.cn_sq[((int64_t)(2 * j) << d.tp_shift) + t];
+            acc1 += d.cn_sq[((int64_t)(2 * j + 1) << d.tp_shift) + t];
         }
-        if (own1) {
+    } else {
+        for (int j = j0; j < j1; ++j) {
+            const int fk = d.cidx[j];
+            const int f = fk / 3;
+            const double D = d.c_D[j];
+            double q[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double w = D * (sB * d.B[idxF(d, f, c, t + 1)] - d.bm[idxM(d, fk, 1, c, t)]);
-                acc1 += w * w;
+            for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * d.B[idxF(d, f, c, t)], d.bm[idxM(d, fk, 0, c, t)]);
+            acc0 += sum3(q[0], q[1], q[2]);
+            if (own1) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * d.B[idxF(d, f, c, t + 1)], d.bm[idxM(d, fk, 1, c, t)]);
+                acc1 += sum3(q[0], q[1], q[2]);
             }
         }
+        if (!own1) acc1 = d.nsq_hi[v];
     }
-    if (!own1) acc1 = d.nsq_hi[v];
     const double acc = acc0 + acc1;
     const double a = d.A[iv];
     const double w_fst = cd - sz * a - d.bf[iv];
@@ -98,7 +113,8 @@ __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double s
 // half the waves for the same bytes (see k_q_lambda_mult_triangle2).  Interval for interval the arithmetic of soc_element.
 // STAGED: the rows of B come from LDS (`rows`: the tile's distinct triangles, [position][c][ldr]; `c_loc`: the position of a
 // corner-list entry's triangle) instead of from memory (k_rhs_soc_tiles): the same values, the same arithmetic.
-template <bool STAGED>
+// CARRIED: see soc_element -- one 16-byte load per corner and half (the s = 1 shares are stored in the column of their INTERVAL).
+template <bool STAGED, bool CARRIED = false>
 __device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double sz, double cd, const double *rows = nullptr, int ldr = 0,
                                              const int *__restrict__ c_loc = nullptr) {
     const double sB = sz * INV_SQRT3;
@@ -106,7 +122,17 @@ __device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double 
     const bool two = t + 1 < d.ni;                 // the second interval exists (T odd: not for the last pair)
     const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
     double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
-    for (int j = j0; j < j1; ++j) {
+    if (CARRIED) {
+        const double *__restrict__ q = d.cn_sq + ((int64_t)(2 * j0) << d.tp_shift) + t;
+        for (int j = j0; j < j1; ++j, q += 2 * d.TP) {
+            const D2 q0 = ld2(q), q1 = ld2(q + d.TP);
+            a0[0] += q0.v[0];
+            a1[0] += q1.v[0];
+            a0[1] += q0.v[1];
+            a1[1] += q1.v[1];
+        }
+    }
+    for (int j = CARRIED ? j1 : j0; j < j1; ++j) {
         const int fk = d.cidx[j];
         const int f = fk / 3;
         const double D = d.c_D[j];
@@ -126,26 +152,19 @@ __device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double 
             m1a[c] = d.bm[idxM(d, fk, 1, c, t)];
             m1b[c] = two ? d.bm[idxM(d, fk, 1, c, t + 1)] : 0.0;
         }
+        double q[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double w = D * (sB * bt[c].v[0] - m0[c].v[0]);
-            a0[0] += w * w;
-        }
+        for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * bt[c].v[0], m0[c].v[0]);
+        a0[0] += sum3(q[0], q[1], q[2]);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double w = D * (sB * bt[c].v[1] - m1a[c]);
-            a1[0] += w * w;
-        }
+        for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * bt[c].v[1], m1a[c]);
+        a1[0] += sum3(q[0], q[1], q[2]);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double w = D * (sB * bt[c].v[1] - m0[c].v[1]);
-            a0[1] += w * w;
-        }
+        for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * bt[c].v[1], m0[c].v[1]);
+        a0[1] += sum3(q[0], q[1], q[2]);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double w = D * (sB * b2[c] - m1b[c]);
-            a1[1] += w * w;
-        }
+        for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * b2[c], m1b[c]);
+        a1[1] += sum3(q[0], q[1], q[2]);
     }
     const D2 A = ld2(d.A + iv), bf = ld2(d.bf + iv), be = ld2(d.be + iv);
     D2 zf, ze, lm;
@@ -173,7 +192,7 @@ __device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double 
     }
 }
 
-template <bool ONLY_MULTIPLIER>
+template <bool ONLY_MULTIPLIER, bool CARRIED = false>
 __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, double cd, int n_soc, int IC) {
     // Workgroups [n_soc, gridDim.x): the modes -> time transform of phi (independent of the projection, same launch)
     if ((int)blockIdx.x >= n_soc) {
@@ -200,7 +219,7 @@ __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, doub
     for (int e = (blockIdx.x / G8) * BLOCK + threadIdx.x; e < TILE_ELEMS; e += TILE_ELEMS) {
         const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
         if (v >= d.V || t >= d.ni) continue;
-        soc_element<ONLY_MULTIPLIER>(d, v, t, sz, cd);
+        soc_element<ONLY_MULTIPLIER, CARRIED>(d, v, t, sz, cd);
     }
 }
 
@@ -245,7 +264,9 @@ int launch_soc_projection(Ctx *c, int zmid_mode, bool with_inverse) {
     const int n_inv = with_inverse ? xcd_grid(c->d.n_vtiles) : 0;
     const size_t lds = with_inverse ? time_modes_tile_lds(c->d) : 0;
     const int IC = time_modes_chunk(c->d);
-    if (zmid_mode)
+    if (zmid_mode && c->carry_valid)
+        hipLaunchKernelGGL((k_soc_projection<true, true>), dim3(n_soc + n_inv), dim3(BLOCK), lds, c->stream, c->d, c->prm.scale_z, c->prm.const_d, n_soc, IC);
+    else if (zmid_mode)
         hipLaunchKernelGGL((k_soc_projection<true>), dim3(n_soc + n_inv), dim3(BLOCK), lds, c->stream, c->d, c->prm.scale_z, c->prm.const_d, n_soc, IC);
     else
         hipLaunchKernelGGL((k_soc_projection<false>), dim3(n_soc + n_inv), dim3(BLOCK), lds, c->stream, c->d, c->prm.scale_z, c->prm.const_d, n_soc, IC);
@@ -260,6 +281,7 @@ int launch_soc_projection(Ctx *c, int zmid_mode, bool with_inverse) {
 // div_x is a gather over the vertex's corner list (no scatter, no atomics).  Each workgroup also
 // emits the partial sum of b (mean removal for the singular eps = 0 operator).
 // ------------------------------------------------------------------------------------------
+template <bool CARRIED = false>
 __device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r, double eps) {
     const int iv = idxV(d, v, t);
     const double m = d.mass_v[v];
@@ -270,12 +292,18 @@ __device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r
     else if (has_prev_interval(d, t)) xm = d.X_lo[v] * m;      // interval t0 - 1 lives in the previous time slab
     double rhs = (xt - xm) * ih;
     double ds = 0.0;
-    for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
-        const int f = d.cidx[j] / 3;
+    if (CARRIED) {      // the corners' shares of div_x((B - E) area) were stored by the last steps-2+3 launch (cn_g[j][node])
+        for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) ds += d.cn_g[((int64_t)j << d.tp_shift) + t];
+    } else {
+        for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+            const int f = d.cidx[j] / 3;
+            double g[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int64_t i = idxF(d, f, c, t);
-            ds += d.c_gA[j * 3 + c] * (d.B[i] - d.E[i]);
+            for (int c = 0; c < 3; ++c) {
+                const int64_t i = idxF(d, f, c, t);
+                g[c] = d.c_gA[j * 3 + c] * (d.B[i] - d.E[i]);
+            }
+            ds += sum3(g[0], g[1], g[2]);
         }
     }
     rhs -= ds;
@@ -344,7 +372,7 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double ep
 // The right-hand side at the nodes t and t + 1 (t even) of a vertex by one lane (one GPU), node for node the arithmetic of
 // rhs_value: B and E of both nodes in one 16-byte word per row.
 // STAGED: B - E of the tile's distinct triangles comes from LDS (see soc_element2).
-template <bool STAGED>
+template <bool STAGED, bool CARRIED = false>
 __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r, double eps, double (&out)[2], const double *rows = nullptr, int ldr = 0,
                                            const int *__restrict__ c_loc = nullptr) {
     const int iv = idxV(d, v, t);
@@ -356,7 +384,16 @@ __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r,
     const double x1 = t + 1 < d.ni ? (A.v[1] + L.v[1] - M.v[1]) * m : 0.0;                  // interval t + 1
     double rhs[2] = {(x0 - xp) * ih, (x1 - x0) * ih};
     double ds[2] = {0.0, 0.0};
-    for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
+    const int jc0 = d.cptr[v], jc1 = d.cptr[v + 1];
+    if (CARRIED) {
+        const double *__restrict__ g = d.cn_g + ((int64_t)jc0 << d.tp_shift) + t;
+        for (int j = jc0; j < jc1; ++j, g += d.TP) {
+            const D2 gj = ld2(g);
+            ds[0] += gj.v[0];
+            ds[1] += gj.v[1];
+        }
+    }
+    for (int j = CARRIED ? jc1 : jc0; j < jc1; ++j) {
         const int f = d.cidx[j] / 3;
         D2 b[3], e[3];
         double ga[3];
@@ -371,11 +408,14 @@ __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r,
                 e[c] = ld2(d.E + i);
             }
         }
+        double g0[3], g1[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            ds[0] += ga[c] * (STAGED ? b[c].v[0] : b[c].v[0] - e[c].v[0]);
-            ds[1] += ga[c] * (STAGED ? b[c].v[1] : b[c].v[1] - e[c].v[1]);
+            g0[c] = ga[c] * (STAGED ? b[c].v[0] : b[c].v[0] - e[c].v[0]);
+            g1[c] = ga[c] * (STAGED ? b[c].v[1] : b[c].v[1] - e[c].v[1]);
         }
+        ds[0] += sum3(g0[0], g0[1], g0[2]);
+        ds[1] += sum3(g1[0], g1[1], g1[2]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -389,6 +429,7 @@ __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r,
 
 // k_rhs_modes with two time columns per lane (one GPU, direct solver): 512 threads per tile.
 constexpr int RHS_NB2 = RHS_NB / 2;
+template <bool CARRIED>
 __global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double eps, double *__restrict__ bhat, int IC, int n_rhs, double sz, double cd,
                                                         const int *__restrict__ tile_vertex) {
     // tile_vertex (or null): the tiles' vertices taken from dots_problem_desc.patch_order instead of from the numbering
@@ -397,7 +438,7 @@ __global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double 
         const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
         if (st >= d.n_vtiles) return;
         const int v = tile_vertex ? tile_vertex[st * d.VT + vl] : (st * d.VT + vl < d.V ? st * d.VT + vl : -1);
-        if (v >= 0 && t < d.ni) soc_element2<false>(d, v, t, sz, cd);
+        if (v >= 0 && t < d.ni) soc_element2<false, CARRIED>(d, v, t, sz, cd);
         return;
     }
     extern __shared__ double tm_lds[];
@@ -413,7 +454,7 @@ __global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double 
         const int vv = ee >> d.tp_shift, tt = ee & (TP - 1);
         const int v = tv ? tv[vv] : (v0 + vv < d.V ? v0 + vv : -1);
         double b[2] = {0.0, 0.0};
-        if (v >= 0 && tt < n) rhs_value2<false>(d, v, tt, r, eps, b);
+        if (v >= 0 && tt < n) rhs_value2<false, CARRIED>(d, v, tt, r, eps, b);
         xs[vv * TPp + tt] = b[0];
         xs[vv * TPp + tt + 1] = tt + 1 < n ? b[1] : 0.0;
     }
@@ -479,12 +520,13 @@ __global__ __launch_bounds__(TILE2_NB) void k_rhs_soc_tiles(Dev d, TileDev tl, d
 }
 
 // T + 1 >= 64: 32 vertices per workgroup, the transform on the matrix cores.
+template <bool CARRIED>
 __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, double eps, double *__restrict__ bhat, int n_rhs, int n_tiles, double sz, double cd) {
     if ((int)blockIdx.x >= n_rhs) {      // riders: the cone projection of a tile, as in k_rhs_modes
         const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
         if (st >= d.n_vtiles) return;
         const int e = threadIdx.x, v = st * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (v < d.V && t < d.ni) soc_element<true>(d, v, t, sz, cd);
+        if (v < d.V && t < d.ni) soc_element<true, CARRIED>(d, v, t, sz, cd);
         return;
     }
     extern __shared__ double xs_m[];                    // [TM_ROWS][TP + 1]
@@ -494,7 +536,7 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, doub
     const int v0 = tile * TM_ROWS;
     for (int e = threadIdx.x; e < TM_ROWS * TP; e += RHS_NB) {
         const int vl = e >> d.tp_shift, t = e & (TP - 1);
-        xs_m[vl * TPp + t] = (v0 + vl < d.V && t < n) ? rhs_value(d, v0 + vl, t, r, eps) : 0.0;
+        xs_m[vl * TPp + t] = (v0 + vl < d.V && t < n) ? rhs_value<CARRIED>(d, v0 + vl, t, r, eps) : 0.0;
     }
     __syncthreads();
     modes_from_tile_mfma<RHS_NB / 64>(d, d.Qpad, xs_m, v0, bhat);
@@ -519,9 +561,16 @@ int launch_rhs(Ctx *c, bool with_soc) {
     const int g = xcd_grid(c->d.n_vtiles);
     if (rhs_writes_modes(c) && time_modes_mfma_ok(c->d)) {      // (two time columns per lane measured here too: knot63 -1.5 %, torus65k_T127 +1.5 %: not kept)
         const int n_tiles = (c->d.V + TM_ROWS - 1) / TM_ROWS, n_rhs = xcd_grid(n_tiles);
-        hipLaunchKernelGGL(k_rhs_modes_mfma, dim3(n_rhs + (with_soc ? g : 0)), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
-                           c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, n_tiles, c->prm.scale_z, c->prm.const_d);
+        if (c->carry_valid)
+            hipLaunchKernelGGL(k_rhs_modes_mfma<true>, dim3(n_rhs + (with_soc ? g : 0)), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
+                               c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, n_tiles, c->prm.scale_z, c->prm.const_d);
+        else
+            hipLaunchKernelGGL(k_rhs_modes_mfma<false>, dim3(n_rhs + (with_soc ? g : 0)), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
+                               c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, n_tiles, c->prm.scale_z, c->prm.const_d);
     }
+    else if (rhs_writes_modes(c) && c->rhs_two && c->d.TP >= 4 && c->carry_valid)      // the corners' shares come from the last steps-2+3 launch
+        hipLaunchKernelGGL(k_rhs_modes2<true>, dim3(with_soc ? 2 * g : g), dim3(RHS_NB2), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
+                           c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d, (const int *)nullptr);
     else if (rhs_writes_modes(c) && c->rhs_two && rhs_on_tiles(c)) {     // patch tiles, triangle rows staged in LDS (large meshes)
         const TileDev &tl = c->tiles;
         const int IC = time_modes_chunk(c->d), gt = xcd_grid(tl.n_tiles);
@@ -538,7 +587,7 @@ int launch_rhs(Ctx *c, bool with_soc) {
                                 IC, c->prm.scale_z, c->prm.const_d);
     }
     else if (rhs_writes_modes(c) && c->rhs_two && c->d.TP >= 4)      // two time columns per lane (16-byte accesses)
-        hipLaunchKernelGGL(k_rhs_modes2, dim3(with_soc ? 2 * g : g), dim3(RHS_NB2), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
+        hipLaunchKernelGGL(k_rhs_modes2<false>, dim3(with_soc ? 2 * g : g), dim3(RHS_NB2), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
                            c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d,
                            (c->rhs_tiles == 2 && c->tiles.n_tiles > 0) ? c->tiles.vertex : (const int *)nullptr);
     else if (rhs_writes_modes(c))
@@ -567,13 +616,13 @@ int launch_rhs(Ctx *c, bool with_soc) {
 // ------------------------------------------------------------------------------------------
 // QONLY: only the (q, lambda_c) closed form (the reference's "Step 0" of is_palm = True, solver_socp.py:668-672):
 // A, B and lambda_c are written, no multiplier moves.
-template <bool QONLY>
+template <bool QONLY, int NB = BLOCK>
 __device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, double sz, double cd, double cr, double tau) {
     const int v0 = tile * d.VT;
     const double a1 = sz * (1.0 + cr);
     const double a2 = 1.0 + 2.0 * sz * a1;
     const double ia2 = 1.0 / a2, a12 = a1 / a2, cl = cr / (1.0 + cr), ih = 1.0 / d.h;
-    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += NB) {
         const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
         if (v >= d.V || t >= d.ni) continue;
         const int iv = idxV(d, v, t);
@@ -680,6 +729,134 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
 // the small meshes (time ~ waves x chain / resident waves).  Element for element the arithmetic of k_q_lambda_mult_triangle.
 // (118 VGPRs = 4 waves per SIMD.  Forcing 5 / 6 with amdgpu_waves_per_eu spills 44 / 132 bytes per lane and loses: torus100k 571 -> 553 / 472 it/s,
 // knot 10 530 -> 9 750 / 7 980: profiles/studies/r03_steps23_forced_occupancy.txt)
+// The lane of k_q_lambda_mult_triangle2 (below) as a function, statement for statement the same arithmetic; that kernel keeps its
+// own copy: the register allocation of its ZMODE = 2 instantiation (118 VGPRs = 4 waves per SIMD) did not survive the call.
+// CARRY (k_q_lambda_mult_carry): the lane also forms, from the registers that hold the NEW B, E and beta_mid, what the next
+// iteration's right-hand side and cone projection would gather from memory -- per corner k of its triangle and node u its
+// xyz component's share of  |D (sB B - beta_mid)|^2  (both halves: s = 0 of interval t + u, s = 1 of interval t + u - 1) and of
+// area * hat . (B - E) -- and leaves them in LDS (xl: this lane's column, stride NBX) for the fold over xyz.
+constexpr int CARRY_NB = 192;         // 3 wavefronts: 2 * 192 / TP rows = whole triangles for every pitch <= 128
+constexpr int CARRY_VALUES = 18;      // per lane: 3 corners x (2 halves + 1 divergence share) x 2 nodes
+template <int ZMODE, bool QONLY, bool CARRY>
+__device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, double sB, double diag_in, double diag_bd, double tau, double *xl = nullptr) {
+    const bool two = t + 1 < d.nl;                  // the second node exists (always, unless the slab holds an odd number of nodes)
+    const int64_t ie = idxF(d, f, c, t);
+    int vk[3];
+    double hk[3], Dk[3];
+    D2 phik[3], l0[3], b0[3], b1[3], z0[3], z1[3];
+    double lm1[3];                                  // the multiplier of interval t - 1 (that of interval t is l0[.].v[0])
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        vk[k] = d.tri[f * 3 + k];
+        hk[k] = d.hat[(f * 3 + k) * 3 + c];
+        Dk[k] = (ZMODE || CARRY) ? d.fk_D[f * 3 + k] : 1.0;
+    }
+    const double area = CARRY ? d.area_f[f] : 0.0;
+    const bool has1_0 = has_prev_interval(d, t);
+    D2 Bold = {{0.0, 0.0}};
+    if (ZMODE) Bold = ld2(d.B + ie);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        phik[k] = ld2(d.phi + idxV(d, vk[k], t));
+        b0[k] = ld2(d.bm + idxM(d, f * 3 + k, 0, c, t));
+        b1[k] = ld2(d.bm + idxM(d, f * 3 + k, 1, c, t - 1));
+        if (ZMODE) {
+            l0[k] = ld2(d.lamc + idxV(d, vk[k], t));
+            const double *pl = t > 0 ? d.lamc + idxV(d, vk[k], t - 1) : (has1_0 ? d.lamc_lo + vk[k] : d.lamc + idxV(d, vk[k], t));
+            lm1[k] = *pl;
+        } else {
+            z0[k] = ld2(d.zm + idxM(d, f * 3 + k, 0, c, t));
+            z1[k] = ld2(d.zm + idxM(d, f * 3 + k, 1, c, t - 1));
+        }
+    }
+    const D2 Eo = ld2(d.E + ie);
+    D2 Bn, En, n0[3], n1[3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int tu = t + u;
+        const bool has0 = tu < d.ni, has1 = has_prev_interval(d, tu);
+        double gx = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gx += hk[k] * phik[k].v[u];
+        double S = 0.0;
+        const double sBold = sB * Bold.v[u];
+        double zz0[3], zz1[3], bb0[3], bb1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bb0[k] = b0[k].v[u];
+            bb1[k] = b1[k].v[u];
+            if (ZMODE) {
+                const double l1 = u == 0 ? lm1[k] : l0[k].v[0];
+                zz0[k] = (l0[k].v[u] / Dk[k]) * (Dk[k] * (sBold - bb0[k]));
+                zz1[k] = (l1 / Dk[k]) * (Dk[k] * (sBold - bb1[k]));
+            } else {
+                zz0[k] = z0[k].v[u];
+                zz1[k] = z1[k].v[u];
+            }
+            if (!has0) zz0[k] = bb0[k] = 0.0;
+            if (!has1) zz1[k] = bb1[k] = 0.0;
+            z0[k].v[u] = zz0[k];
+            z1[k].v[u] = zz1[k];
+            S += (zz0[k] + bb0[k]) + (zz1[k] + bb1[k]);
+        }
+        const double bn = (gx + Eo.v[u] + sB * S) / ((first_node(d, tu) || last_node(d, tu)) ? diag_bd : diag_in);
+        Bn.v[u] = bn;
+        En.v[u] = Eo.v[u] + tau * (gx - bn);
+        const double sBn = sB * bn;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            // slots whose interval does not exist keep what they hold (zeros): the scalar kernel does not store them either
+            n0[k].v[u] = has0 ? bb0[k] + tau * (zz0[k] - sBn) : b0[k].v[u];
+            n1[k].v[u] = has1 ? bb1[k] + tau * (zz1[k] - sBn) : b1[k].v[u];
+        }
+        if (CARRY) {      // the expressions of soc_element2 / rhs_value2 on the values those will find in memory
+            const bool node = tu < d.nl;
+            const double de = bn - En.v[u];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                xl[(k * 6 + u) * CARRY_NB] = has0 ? soc_w2(Dk[k], sBn, n0[k].v[u]) : 0.0;               // s = 0 half of interval tu
+                xl[(k * 6 + 2 + u) * CARRY_NB] = (has1 && node) ? soc_w2(Dk[k], sBn, n1[k].v[u]) : 0.0;  // s = 1 half of interval tu - 1
+                xl[(k * 6 + 4 + u) * CARRY_NB] = node ? (hk[k] * area) * de : 0.0;                       // div_x share at node tu
+            }
+        }
+    }
+    if (two) {
+        if (ZMODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // (entries of intervals that do not exist are stored as the zeros computed above; their slots are never read as data)
+                st2(d.zm + idxM(d, f * 3 + k, 0, c, t), z0[k]);
+                st2(d.zm + idxM(d, f * 3 + k, 1, c, t - 1), z1[k]);
+            }
+        }
+        st2(d.B + ie, Bn);
+        if (QONLY) return;
+        st2(d.E + ie, En);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            st2(d.bm + idxM(d, f * 3 + k, 0, c, t), n0[k]);
+            st2(d.bm + idxM(d, f * 3 + k, 1, c, t - 1), n1[k]);
+        }
+    } else {      // only the first node of the pair exists: element-wise stores
+        const bool has0 = t < d.ni, has1 = has1_0;
+        if (ZMODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (has0) d.zm[idxM(d, f * 3 + k, 0, c, t)] = z0[k].v[0];
+                if (has1) d.zm[idxM(d, f * 3 + k, 1, c, t - 1)] = z1[k].v[0];
+            }
+        }
+        d.B[ie] = Bn.v[0];
+        if (QONLY) return;
+        d.E[ie] = En.v[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (has0) d.bm[idxM(d, f * 3 + k, 0, c, t)] = n0[k].v[0];
+            if (has1) d.bm[idxM(d, f * 3 + k, 1, c, t - 1)] = n1[k].v[0];
+        }
+    }
+}
+
 template <int ZMODE, bool QONLY = false>
 __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle2(Dev d, double sz, double tau, int nf8, double cd, double cr) {
     constexpr int SUB = TILE_ELEMS / (2 * BLOCK);     // two elements per thread: a workgroup takes half of a triangle tile
@@ -804,6 +981,53 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle2(Dev d, double
     }
 }
 
+// Steps 2+3 that also CARRY the next iteration's gathers (DOTS_STEP_CARRY; one GPU, pitch <= 128).  A workgroup of 192 lanes takes
+// whole triangles (the three xyz rows of a triangle are TP / 2 lanes apart), the lanes exchange their shares through LDS and the
+// lane of component c folds corner k = c over xyz -- (x + y) + z, the association of sum3 -- and stores
+//     cn_sq[j][0][interval]   the s = 0 half of |D (sB B - beta_mid)|^2 of corner-list entry j,
+//     cn_sq[j][1][interval]   the s = 1 half (formed at node interval + 1: it comes from the next lane of the row),
+//     cn_g[j][node]           area * hat_k . (B - E),
+// j = cpos[f * 3 + k]: the rows of a vertex's corners are CONTIGUOUS, so the next right-hand-side / projection launch streams
+// them (soc_element2 / rhs_value2 <CARRIED>) instead of walking index lists into B, E and beta_mid.
+// Replaces one of the three passes over beta_mid per iteration (solver_socp.py:997-1017 reads what :716-722 just wrote).
+#ifdef DOTS_CARRY_WAVES      // A/B: -DDOTS_CARRY_WAVES=4 caps the registers at 128 (20 spilled); default: 148 VGPRs = 3 waves per SIMD
+#define CARRY_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DOTS_CARRY_WAVES)))
+#else
+#define CARRY_OCCUPANCY
+#endif
+template <int ZMODE>
+__global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carry(Dev d, double sz, double tau, int n_fwg, int tri_per_wg, double cd, double cr) {
+    __shared__ double xs[CARRY_VALUES * CARRY_NB];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= n_fwg) {
+        const int vt = xcd_tile(blockIdx.x - n_fwg, d.n_vtiles);
+        if (vt < d.n_vtiles) q_lambda_vertex_tile<false, CARRY_NB>(d, vt, sz, cd, cr, tau);
+        return;
+    }
+    const int wg = xcd_tile(blockIdx.x, (d.F + tri_per_wg - 1) / tri_per_wg);
+    const int e = 2 * tid, lr = e >> d.tp_shift, t = e & (d.TP - 1);      // local row (3 per triangle), first node
+    const int f = wg * tri_per_wg + lr / 3, c = lr - 3 * (lr / 3);
+    const bool active = f < d.F && t < d.nl;      // (a whole triangle is active or not; so is a column over its three rows)
+    if (active) ql2_lane<ZMODE, false, true>(d, f, c, t, sz * INV_SQRT3, 1.0 + 2.0 * sz * sz, 1.0 + sz * sz, tau, xs + tid);
+    __syncthreads();
+    const int L = d.TP >> 1;                      // lanes per row
+    const int t0 = tid - c * L;                   // the lane of component 0 of this triangle and column
+    double q[6];                                  // corner k = c: s = 0 halves (nodes t, t + 1), s = 1 halves, divergence shares
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double *x = xs + (c * 6 + i) * CARRY_NB + t0;
+        q[i] = active ? sum3(x[0], x[L], x[2 * L]) : 0.0;
+    }
+    // q[2], q[3]: s = 1 halves of the intervals t - 1 and t.  Stored by interval: (t, t + 1) = (own q[3], the next lane's q[2]);
+    // the row's last lane (t = TP - 2) would need interval TP - 1 >= T, which does not exist.
+    const double nxt = __shfl_down(q[2], 1, 64);
+    if (!active) return;
+    const int j = d.cpos[f * 3 + c];
+    st2(d.cn_sq + ((int64_t)(2 * j) << d.tp_shift) + t, D2{{q[0], q[1]}});
+    st2(d.cn_sq + ((int64_t)(2 * j + 1) << d.tp_shift) + t, D2{{q[3], t + 2 < d.TP ? nxt : 0.0}});
+    st2(d.cn_g + ((int64_t)j << d.tp_shift) + t, D2{{q[4], q[5]}});
+}
+
 // Step 0 of is_palm = True: (A, B, lambda_c) from the current multipliers and the stored z_mid; nothing else moves.
 int launch_q_lambda_only(Ctx *c) {
     const dots_params &p = c->prm;
@@ -818,6 +1042,16 @@ int launch_q_lambda_mult(Ctx *c, int zmid_mode) {
     const dots_params &p = c->prm;
     const int nf8 = xcd_grid(c->d.n_ftiles), nv8 = xcd_grid(c->d.n_vtiles);
     const double cd = p.const_d, cr = p.congestion * p.r;
+    c->carry_valid = 0;
+    if (carry_possible(c) && c->step_carry && zmid_mode >= 1) {      // ... and the next iteration's gathers are formed here (k_q_lambda_mult_carry)
+        const int tw = (2 * CARRY_NB / c->d.TP) / 3, n_fwg = xcd_grid((c->d.F + tw - 1) / tw);
+        const dim3 g(n_fwg + nv8);
+        if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_carry<2>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr);
+        else hipLaunchKernelGGL((k_q_lambda_mult_carry<1>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr);
+        DOTS_HIP(hipGetLastError());
+        c->carry_valid = 1;
+        return 0;
+    }
     if (c->ql_two && c->d.TP >= 4) {      // two nodes per lane (16-byte accesses): k_q_lambda_mult_triangle2
         const dim3 g2(nf8 * (TILE_ELEMS / (2 * BLOCK)) + nv8);
         if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_triangle2<2>), g2, dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr);
@@ -1087,11 +1321,13 @@ int launch_operator(Ctx *c, int op, double scale, const double *in, double *out)
 // the context is created, not inside the first iterations that happen to use them.
 void preload_alm_kernels() {
     const void *fns[] = {
-        (const void *)k_rhs, (const void *)k_rhs_modes, (const void *)k_rhs_modes2, (const void *)k_rhs_modes_mfma,
-        (const void *)k_soc_projection<true>, (const void *)k_soc_projection<false>,
+        (const void *)k_rhs, (const void *)k_rhs_modes, (const void *)k_rhs_modes2<false>, (const void *)k_rhs_modes2<true>,
+        (const void *)k_rhs_modes_mfma<false>, (const void *)k_rhs_modes_mfma<true>,
+        (const void *)k_soc_projection<true>, (const void *)k_soc_projection<false>, (const void *)k_soc_projection<true, true>,
         (const void *)k_q_lambda_mult_triangle<0>, (const void *)k_q_lambda_mult_triangle<1>, (const void *)k_q_lambda_mult_triangle<2>,
         (const void *)k_q_lambda_mult_triangle<0, true>,
         (const void *)k_q_lambda_mult_triangle2<0>, (const void *)k_q_lambda_mult_triangle2<1>, (const void *)k_q_lambda_mult_triangle2<2>,
+        (const void *)k_q_lambda_mult_carry<1>, (const void *)k_q_lambda_mult_carry<2>,
         (const void *)k_divide_five, (const void *)k_scale, (const void *)k_divide, (const void *)k_rebuild_mu, (const void *)k_rebuild_E,
     };
     hipFuncAttributes a;

@@ -88,6 +88,7 @@ class AlmSolver:
                               and (ahead == "2" or (int(n_time) + 1 < 64
                                                     and np.asarray(geometry["vertices"]).shape[0] * (int(n_time) + 1) <= 200_000)))
         self._rhs_ahead = False
+        self._carry = False             # DOTS_STEP_CARRY for the next device step (iterate())
         if direct and reorder is True:
             reorder = "nd"      # the elimination order of the factor doubles as the locality numbering
         self.dev = dev = DeviceProblem(n_time, geometry, lap_solver="modal_pcg" if direct else lap_solver, device=device,
@@ -300,7 +301,8 @@ class AlmSolver:
             self.quiet_steps += 1
         if self.direct:
             timed = sample and len(self._timed_in_flight) < 60       # (the ring of the library holds 64 slots)
-            self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, rhs_ahead=self._rhs_ahead and not quiet, timed=timed)
+            self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, rhs_ahead=self._rhs_ahead and not quiet, timed=timed,
+                                carry=self._carry)
             self.dev.step(1, wait=False)
             if timed:
                 self._timed_in_flight.append(kind)
@@ -363,6 +365,10 @@ class AlmSolver:
         # dropped by the library if anything changes in between).
         self._rhs_ahead = (self._rhs_ahead_ok and reads_back and not is_time_used_up and it + 1 < self.nit
                            and not params.peek_adjust(it))
+        # The next iteration starts from the state this one leaves unless the penalty is updated in between (known from the schedule;
+        # a z rescaling or a stop simply drop what was carried): steps 2+3 then also store the per-corner sums that iteration's
+        # right-hand side and cone projection would gather from B, E and beta_mid (DOTS_STEP_CARRY: one pass over beta_mid less).
+        self._carry = self.direct and not self.is_palm and it + 1 < self.nit and not params.peek_adjust(it)
         self._device_step(quiet)                                                # steps 1-3 (:674-722)
 
         adjust = params.is_to_adjust(it) or is_time_used_up

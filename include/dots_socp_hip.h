@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DOTS_ABI_VERSION 6
+#define DOTS_ABI_VERSION 7
 
 typedef struct dots_ctx dots_ctx;
 
@@ -191,6 +191,14 @@ int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
  * the finished slots later, oldest first (the reference's per-step timers, utils/admm_tools.py:244-251, without a host wait in
  * the loop).  A step that finds the ring full is simply not timed. */
 #define DOTS_STEP_TIMED 8u
+/* DOTS_STEP_CARRY (a hint: ignored without the direct solver, on a time slab, with DOTS_STEP_PALM or a time pitch above 128): the caller
+ * expects the NEXT iteration to start from the state this step leaves.  Steps 2+3 then also store, per corner of every triangle,
+ * what the next right-hand side (solver_socp.py:983-986: div_x((B - E) area)) and the next cone projection (:997-1017: the squared
+ * norm of D (L B - beta_mid)) would gather from B, E and beta_mid -- they hold those values in registers when they write them
+ * (:716-722) -- and the next dots_step streams these per-corner sums instead of reading beta_mid a third time.  Any call in
+ * between that changes the state or the parameters drops them and the step gathers from the arrays again: results never depend
+ * on the flag, bit for bit (both paths form the same sums in the same order). */
+#define DOTS_STEP_CARRY 16u
 int dots_step_flags(dots_ctx *ctx, uint32_t flags);      /* also apply to dots_slab_stage */
 /* The phase times of the timed steps that have finished (wait != 0: of all timed steps, waiting for them), oldest first, at
  * most `capacity`: one dots_step_stats per dots_step iteration (alm_iterations = 1), or one per slab stage (the stage's time in

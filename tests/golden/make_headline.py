@@ -27,6 +27,9 @@ WORKLOADS = {   # same table as bench.py
     "knot": dict(example="knot", kw={}, n_time=31, congestion=0.0, tol=1e-3),
     "knot63": dict(example="knot", kw={}, n_time=63, congestion=0.1, tol=1e-3),
     "torus100k": dict(example="torus", kw=dict(nu=400, nv=250), n_time=31, congestion=0.0, tol=1e-3),
+    # BASELINE configs[3] (the north star's size) recorded from the REFERENCE itself, truncated like configs[4] below: the full
+    # 282 iterations would take the reference many hours; `headline_torus100k.npz` (the oracle's full-length run) stays beside it
+    "torus100k_ref10": dict(example="torus", kw=dict(nu=400, nv=250), n_time=31, congestion=0.0, tol=1e-3, nit=10, check_kkt_step_by_step=True),
     # BASELINE configs[4] stand-in at its full size; the reference needs ~1 min per iteration there, so the run is
     # TRUNCATED: the first `nit` iterations with every KKT residual and the objective recorded each iteration
     "torus65k_T127": dict(example="torus", kw=dict(nu=360, nv=180), n_time=127, congestion=0.0, tol=1e-5, nit=10, check_kkt_step_by_step=True),

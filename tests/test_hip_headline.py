@@ -1,6 +1,6 @@
 """BASELINE.json's configurations at FULL size on the GPU against the runs recorded by tests/golden/make_headline.py
 (the reference itself for sphere10k / knot / knot63 and -- truncated to its first 10 iterations, every KKT residual and
-the objective recorded each iteration -- for torus65k_T127; the CPU oracle for torus100k): same stopping iteration, same
+the objective recorded each iteration -- for torus100k_ref10 and torus65k_T127; the CPU oracle's full-length run for torus100k): same stopping iteration, same
 lazy-KKT pattern, KKT values / cost / objective within 1e-6, sampled solution within 1e-5."""
 import glob
 import os
@@ -17,7 +17,8 @@ WORKLOADS = {
     "sphere10k": dict(example="sphere", kw=dict(level=5)),
     "knot": dict(example="knot", kw={}),
     "knot63": dict(example="knot", kw={}),
-    "torus100k": dict(example="torus", kw=dict(nu=400, nv=250)),
+    "torus100k": dict(example="torus", kw=dict(nu=400, nv=250)),                # the CPU oracle's full-length run (282 iterations)
+    "torus100k_ref10": dict(example="torus", kw=dict(nu=400, nv=250)),          # ... and the REFERENCE itself on the same problem, first 10 iterations
     "torus65k_T127": dict(example="torus", kw=dict(nu=360, nv=180)),      # BASELINE configs[4] stand-in: a TRUNCATED reference run
 }
 FIXTURES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "headline_*.npz")))

@@ -326,6 +326,82 @@ def test_right_hand_side_ahead_is_bit_identical_and_dropped_on_changes():
     dev.close()
 
 
+@pytest.mark.parametrize("fixture,T", [("ops_ico1.npz", None), ("ops_torus8x6.npz", None), ("ops_ico1.npz", 12), ("ops_torus8x6.npz", 31),
+                                       ("ops_refplane4.npz", 63), ("ops_ico1.npz", 64), ("ops_torus8x6.npz", 127)])
+def test_carried_gathers_are_bit_identical_and_dropped_on_changes(fixture, T):
+    """DOTS_STEP_CARRY: steps 2+3 also store, per corner, the sums the next right-hand side and cone projection would gather from
+    B, E and beta_mid; the next step streams them instead (k_q_lambda_mult_carry -> soc_element2 / rhs_value2 <CARRIED>).  Same iterates
+    bit for bit as without the flag -- enqueued and timed steps, with the right-hand side ahead, odd and even numbers of nodes, every
+    time pitch up to 128 (LDS and MFMA transforms) -- and a penalty update, a rescaling, an upload or a single phase in between
+    drops what was carried (the step gathers from the changed arrays)."""
+    from dots_socp_amd.device import DeviceProblem
+
+    g = golden(fixture)
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    T = int(g["n_time"]) if T is None else T
+
+    def run(carry):
+        dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+        dev.setup_frontal(leaf=4)
+        dev.scale_z(2.0, 0.5, 2.0)
+        dev.set_params(scale_z=2.0, const_d=2.0, congestion=0.05)
+        res = []
+        for k in range(16):
+            reads = k % 3 != 1
+            dev.step_flags(skip_z_mid=not reads, rhs_ahead=reads and k % 2 == 0, carry=carry and k != 9)
+            if k in (4, 11):
+                dev.step(1)                             # the synchronous (timed) path: right-hand side, solve, projection + inverse transform
+            else:
+                dev.step(1, wait=False)
+            if reads:
+                res.append(dev.kkt([0, 2, 3]))
+            if k == 3:
+                dev.adjust_penalty(1.7)                 # changes r and five arrays: the carried sums are dropped
+                dev.set_params(r=1.7)
+            if k == 6:
+                dev.scale_z(3.0, 1.0 / 3.0, 3.0)
+                dev.set_params(scale_z=3.0, const_d=3.0)
+            if k == 8:
+                dev.upload("beta_mid", dev.download("beta_mid") * 1.01)
+            if k == 12:
+                dev.run_phase("q_lambda_mult")          # a single phase (no carry): B, E and beta_mid move
+        dev.step_flags(skip_z_mid=False)
+        dev.step(1)
+        out = (dev.download_all(), dev.kkt(range(7)), res)
+        dev.close()
+        return out
+
+    a, b = run(False), run(True)
+    for k in a[0]:
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert a[1] == b[1] and a[2] == b[2]
+
+
+def test_carry_flag_is_a_hint():
+    """DOTS_STEP_CARRY is ignored without the direct solver and with is_palm's step 0 (which moves B before the right-hand side)."""
+    from dots_socp_amd.device import DeviceProblem
+
+    g = golden("ops_ico1.npz")
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    T = int(g["n_time"])
+    dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+    dev.set_params(cg_tol=1e-10)
+    dev.step_flags(carry=True)
+    dev.step(2)
+    assert np.isfinite(dev.kkt([0])[0][0])
+    dev.close()
+    out = []
+    for carry in (False, True):
+        dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+        dev.setup_frontal(leaf=4)
+        dev.step_flags(palm=True, carry=carry)
+        dev.step(5)
+        out.append(dev.download_all())
+        dev.close()
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
+
+
 @pytest.mark.parametrize("fixture", ["ops_ico1.npz", "ops_torus8x6.npz"])
 def test_kkt_sums_with_two_nodes_per_lane(fixture, monkeypatch):
     """The KKT kernels take two nodes per lane on one GPU (kkt_vertex_body2 / kkt_triangle_body2); DOTS_KKT_TWO=0 keeps the one-node
