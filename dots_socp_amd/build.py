@@ -16,9 +16,10 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libdotsocp_hip.so")
 SOURCES = ["dots_api.hip", "kernels_alm.hip", "kernels_cg.hip", "kernels_mg.hip", "kernels_front.hip", "kernels_factor.hip", "dissect.hip", "kernels_kkt.hip"]
+EXPORTS = os.path.join(CSRC, "exports.map")      # linker version script: only dots_* is exported
 HEADERS = [os.path.join(CSRC, "dots_dev.h"), os.path.join(PKG_DIR, "..", "include", "dots_socp_hip.h")]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-ffp-contract=off", "-fvisibility=hidden"]      # (the header's declarations are the exports)
 FLAGS += os.environ.get("DOTS_HIPCC_FLAGS", "").split()      # extra -D switches for A/B measurements of compile-time variants
 
 
@@ -61,7 +62,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     except (OSError, ValueError):
         stamp = {}
     want = {os.path.basename(o): _digest([s] + HEADERS, (FLAGS, tool)) for s, o in zip(srcs, objs)}
-    want[os.path.basename(LIB_PATH)] = hashlib.sha256(repr(sorted(want.items())).encode()).hexdigest()
+    want[os.path.basename(LIB_PATH)] = hashlib.sha256((repr(sorted(want.items())) + open(EXPORTS).read()).encode()).hexdigest()
 
     def stale(path):
         return force or not os.path.exists(path) or stamp.get(os.path.basename(path)) != want[os.path.basename(path)]
@@ -80,7 +81,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         done = [d for d in ex.map(compile_one, zip(srcs, objs)) if d]
     relink = bool(done) or stale(LIB_PATH)
     if relink:
-        r = subprocess.run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs, capture_output=True, text=True)
+        r = subprocess.run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", f"-Wl,--version-script={EXPORTS}", "-o", LIB_PATH] + objs, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if done or relink:

@@ -373,19 +373,23 @@ def safe_rescale_ratio(prim_gap: float, kkt_row) -> float:
 class SampledStepTimers:
     """``RunningHistory.steps_time`` (the reference's per-step timers, utils/admm_tools.py:244-251, printed as "Time of steps"
     at :505-540 and scraped into the paper's Time[s] column by replication/log2table.py:99-106) for a loop that never waits for
-    the device: the phases of SAMPLED iterations are bracketed by events on the stream (DOTS_STEP_TIMED) and collected at
-    the next read-back.  Iterations come in kinds (e.g. "quiet": nothing read back, z_mid not stored; "read-back") that cost
-    differently; the time of a step is estimated as
+    the device: the phases of SAMPLED iterations are bracketed by events on the stream (DOTS_STEP_TIMED; the library takes the
+    measured cost of an event off every phase) and collected at the next read-back.  Iterations come in kinds (e.g. "quiet":
+    nothing read back, z_mid not stored; "read-back") that cost differently, and the first iterations of a run are not typical
+    (cold caches and kernels, a dense KKT / penalty schedule).  So each kind has two strata:
 
-        sum over kinds of  (mean of the sampled iterations of the kind)  x  (iterations of the kind)
+        the first ``first`` iterations of the kind     counted EXACTLY (every one of them is timed)
+        the iterations after them                       (median of the every-``every``-th samples)  x  (their number)
 
-    so its sum is the device time of ALL iterations' steps, not of the sampled ones.  The first ``first`` iterations of a kind
-    and every ``every``-th afterwards are sampled (``every = 1``: all of them, the estimate is then the plain sum)."""
+    and the time of a step is the sum over kinds and strata: the device time of ALL iterations' steps, not of the sampled
+    ones.  Until the second stratum has a sample of its own its iterations are priced at the LAST timed iteration of the
+    kind.  ``every = 1``: every iteration is timed and the estimate is the plain sum."""
 
     def __init__(self, history, first=4, every=8):
         self.history, self.first, self.every = history, int(first), max(1, int(every))
         self.n = {}          # kind -> iterations so far
-        self.sums = {}       # kind -> tag -> [seconds, samples]
+        self.values = {}     # kind -> tag -> [seconds of each timed iteration, oldest first]
+        self.partial = {}    # kind -> tag -> seconds of the timed iteration whose records are still arriving
         self.tags = []
 
     def begin(self, kind):
@@ -394,11 +398,14 @@ class SampledStepTimers:
         return n <= self.first or n % self.every == 0
 
     def add(self, kind, tag, seconds, samples=1):
+        """``samples``: 1 on the record that completes a timed iteration (a time slab reports its stages one by one: the record of
+        its last stage carries 1, the others 0)."""
         if tag not in self.tags:
             self.tags.append(tag)
-        acc = self.sums.setdefault(kind, {}).setdefault(tag, [0.0, 0])
-        acc[0] += seconds
-        acc[1] += samples
+        part = self.partial.setdefault(kind, {})
+        part[tag] = part.get(tag, 0.0) + seconds
+        if samples:
+            self.values.setdefault(kind, {}).setdefault(tag, []).append(part.pop(tag))
 
     def publish(self):
         hist = self.history
@@ -406,16 +413,28 @@ class SampledStepTimers:
         for tag in self.tags:
             est = 0.0
             for kind, n in self.n.items():
-                acc = self.sums.get(kind, {}).get(tag)
-                if acc and acc[1]:
-                    est += acc[0] / acc[1] * n
+                vals = self.values.get(kind, {}).get(tag)
+                if not vals:
+                    continue
+                head, tail = vals[:self.first], vals[self.first:]
+                est += sum(head)
+                rest = n - len(head)
+                if rest <= 0:
+                    continue
+                if len(vals) >= n:                   # every iteration was timed: the plain sum
+                    est += sum(tail)
+                elif tail:
+                    est += float(np.median(tail)) * rest
+                else:                                # no periodic sample yet: the latest timed iteration stands in
+                    est += head[-1] * rest
             hist.steps_time[tag] = est
         for kind, n in self.n.items():
             total += n
-            sampled += max([a[1] for a in self.sums.get(kind, {}).values()] or [0])
+            sampled += max([len(v) for v in self.values.get(kind, {}).values()] or [0])
         if sampled < total:
             hist.steps_time_note = (f"device time of all {total} iterations, estimated per kind of iteration "
-                                    f"({', '.join(f'{n} {k}' for k, n in self.n.items())}) from {sampled} sampled ones: events on the "
-                                    "stream, read after the fact, no host wait in the loop")
+                                    f"({', '.join(f'{n} {k}' for k, n in self.n.items())}) from {sampled} timed ones (the first {self.first} of a kind "
+                                    f"counted exactly, the others at the median of every {self.every}-th): events on the stream, read after the fact, "
+                                    "no host wait in the loop; a launch shared by the right-hand side and the projection is booked half to each")
         else:
             hist.steps_time_note = None

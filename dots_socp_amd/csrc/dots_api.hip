@@ -370,6 +370,7 @@ static int slab_stage(Ctx *c, int stage) {
 }
 
 // a free slot of the timing ring (its events created on first use), or nullptr when the ring is full: the step is then not timed
+constexpr int TKIND_FUSED = 16;      // tkind of a whole iteration whose projection rode in the right-hand-side launch
 static hipEvent_t *time_slot(Ctx *c, int kind) {
     if (!c->step_timed || c->t_count >= Ctx::TIME_SLOTS) return nullptr;
     const int s = (c->t_head + c->t_count) % Ctx::TIME_SLOTS;
@@ -380,9 +381,8 @@ static hipEvent_t *time_slot(Ctx *c, int kind) {
     return c->tev[s];
 }
 
-static int run_iteration(Ctx *c, dots_step_stats *st) {
+static int run_iteration_body(Ctx *c, dots_step_stats *st, hipEvent_t *tv) {
     int rc;
-    hipEvent_t *tv = st ? nullptr : time_slot(c, 0);
 #define MARK(i) do { if (tv) DOTS_HIP(hipEventRecord(tv[i], c->stream)); } while (0)
     MARK(0);
     if ((rc = palm_step0(c))) return rc;
@@ -397,9 +397,11 @@ static int run_iteration(Ctx *c, dots_step_stats *st) {
             MARK(1);
             if ((rc = cg_solve(c, nullptr))) return rc;
             MARK(2);
-            MARK(3);
+            MARK(3);      // (no separate projection launch: dots_step_times splits the first phase between ms_rhs and ms_soc)
             if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
             MARK(4);
+            MARK(5);      // back to back with 4: what one event costs on the stream, taken off every phase (dots_step_times)
+            if (tv) c->tkind[(c->t_head + c->t_count - 1) % Ctx::TIME_SLOTS] = TKIND_FUSED;
             return 0;
         }
         const bool fuse = soc_takes_inverse(c);
@@ -411,6 +413,7 @@ static int run_iteration(Ctx *c, dots_step_stats *st) {
         MARK(3);
         if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
         MARK(4);
+        MARK(5);
         return 0;
     }
 #undef MARK
@@ -434,6 +437,15 @@ static int run_iteration(Ctx *c, dots_step_stats *st) {
     DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[4])); st->ms_total += t;
     st->alm_iterations += 1;
     return 0;
+}
+
+// A slot of the timing ring is taken before the phases are enqueued: if enqueueing fails midway the slot is given back, so that a
+// later dots_step_times never waits on events that were not recorded (and does not hide the original error behind its own).
+static int run_iteration(Ctx *c, dots_step_stats *st) {
+    hipEvent_t *tv = st ? nullptr : time_slot(c, 0);
+    const int rc = run_iteration_body(c, st, tv);
+    if (rc && tv) c->t_count -= 1;
+    return rc;
 }
 
 static void mg_release(Ctx *c) {
@@ -649,9 +661,14 @@ int dots_slab_stage(dots_ctx *c, int stage, dots_step_stats *stats) {
     if (stage == 4 && c->slab_stage != 0) { set_error("slab_stage: the KKT halos are packed between iterations"); return DOTS_ERR_STATE; }
     if (!stats) {
         hipEvent_t *tv = stage <= 3 ? time_slot(c, 1 + stage) : nullptr;
-        if (tv) DOTS_HIP(hipEventRecord(tv[0], c->stream));
-        if ((rc = slab_stage(c, stage))) return rc;
-        if (tv) DOTS_HIP(hipEventRecord(tv[1], c->stream));
+        rc = tv ? (int)hipEventRecord(tv[0], c->stream) : 0;
+        if (!rc) rc = slab_stage(c, stage);
+        if (!rc && tv && hipEventRecord(tv[1], c->stream) != hipSuccess) rc = DOTS_ERR_HIP;
+        if (rc) {      // (the slot goes back to the ring: see run_iteration)
+            if (tv) c->t_count -= 1;
+            if (rc > 0) { set_error("slab_stage: hipEventRecord failed"); rc = DOTS_ERR_HIP; }
+            return rc;
+        }
     } else {
         DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
         if ((rc = slab_stage(c, stage))) return rc;
@@ -661,6 +678,7 @@ int dots_slab_stage(dots_ctx *c, int stage, dots_step_stats *stats) {
         DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
         memset(stats, 0, sizeof *stats);
         stats->ms_total = t;
+        if (stage == 0) stats->ms_rhs = t;                             // packing the halos (as dots_step_times books it)
         if (stage == 1) stats->ms_rhs = stats->ms_soc = 0.5 * t;      // one launch: right-hand side and projection together
         if (stage == 2) { stats->ms_laplacian = t; stats->cg_iterations = stats->cg_last_iterations = c->last_cg_iters; }
         if (stage == 3) { stats->ms_q_lambda_multiplier = t; stats->alm_iterations = 1; }
@@ -718,7 +736,8 @@ int dots_step_times(dots_ctx *c, dots_step_stats *out, int capacity, int wait, i
     while (n < capacity && c->t_count > 0) {
         hipEvent_t *tv = c->tev[c->t_head];
         const int kind = c->tkind[c->t_head];
-        hipEvent_t last = tv[kind == 0 ? 4 : 1];
+        const bool whole = kind == 0 || kind == TKIND_FUSED;
+        hipEvent_t last = tv[whole ? 5 : 1];
         if (wait) DOTS_HIP(hipEventSynchronize(last));
         else {
             const hipError_t q = hipEventQuery(last);
@@ -728,12 +747,25 @@ int dots_step_times(dots_ctx *c, dots_step_stats *out, int capacity, int wait, i
         dots_step_stats &st = out[n];
         memset(&st, 0, sizeof st);
         float t;
-        if (kind == 0) {
-            DOTS_HIP(hipEventElapsedTime(&t, tv[0], tv[1])); st.ms_rhs = t;
-            DOTS_HIP(hipEventElapsedTime(&t, tv[1], tv[2])); st.ms_laplacian = t;
-            DOTS_HIP(hipEventElapsedTime(&t, tv[2], tv[3])); st.ms_soc = t;
-            DOTS_HIP(hipEventElapsedTime(&t, tv[3], tv[4])); st.ms_q_lambda_multiplier = t;
-            DOTS_HIP(hipEventElapsedTime(&t, tv[0], tv[4])); st.ms_total = t;
+        if (whole) {
+            // Every phase is bracketed by two events, and an event costs stream time itself: the gap between the two events
+            // recorded back to back behind the last kernel (4, 5) is that cost, measured in this very iteration; it is taken off
+            // every phase so that the sampled times estimate what the UNTIMED iterations of the kind take.
+            float gap, p[4];
+            DOTS_HIP(hipEventElapsedTime(&gap, tv[4], tv[5]));
+            for (int i = 0; i < 4; ++i) {
+                DOTS_HIP(hipEventElapsedTime(&p[i], tv[i], tv[i + 1]));
+                p[i] = p[i] > gap ? p[i] - gap : 0.0f;
+            }
+            if (kind == TKIND_FUSED) {      // one launch for the right-hand side and the projection: half each, as a slab's stage 1
+                st.ms_rhs = st.ms_soc = 0.5 * p[0];
+            } else {
+                st.ms_rhs = p[0];
+                st.ms_soc = p[2];
+            }
+            st.ms_laplacian = p[1];
+            st.ms_q_lambda_multiplier = p[3];
+            st.ms_total = (double)p[0] + p[1] + (kind == TKIND_FUSED ? 0.0 : (double)p[2]) + p[3];
             st.alm_iterations = 1;
         } else {
             const int stage = kind - 1;

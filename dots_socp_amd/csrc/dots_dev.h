@@ -299,8 +299,8 @@ struct Ctx {
     TileDev tiles{};
     // DOTS_STEP_TIMED: phase events of enqueue-only steps, collected later by dots_step_times (no host wait in the loop)
     static constexpr int TIME_SLOTS = 64;
-    hipEvent_t tev[TIME_SLOTS][5]{};  // created on first use
-    int tkind[TIME_SLOTS]{};      // 0: a whole dots_step iteration (5 events), 1 + stage: one dots_slab_stage (events 0 and 1)
+    hipEvent_t tev[TIME_SLOTS][6]{};  // created on first use
+    int tkind[TIME_SLOTS]{};      // 0 / 16: a whole dots_step iteration (6 events; 16: the projection rode in the right-hand-side launch), 1 + stage: one dots_slab_stage (events 0 and 1)
     int t_head = 0, t_count = 0;  // ring: oldest slot, slots in flight
     int step_timed = 0;           // dots_step_flags
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)

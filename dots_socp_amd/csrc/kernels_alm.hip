@@ -29,6 +29,10 @@ namespace dots {
 // kernels that gather these terms from memory and the steps-2+3 kernel that forms them from its registers for the next
 // iteration (DOTS_STEP_CARRY: cn_sq, cn_g below) then produce the same sums bit for bit (-ffp-contract=off: no fused multiply-adds).
 __device__ __forceinline__ double sum3(double x, double y, double z) { return (x + y) + z; }
+#ifndef DOTS_CARRY_BATCH
+#define DOTS_CARRY_BATCH 2
+#endif
+constexpr int CARRY_BATCH = DOTS_CARRY_BATCH;      // corners whose carried rows a lane loads before it adds them (closed surfaces: valence ~ 6)
 // one pre-image entry of the cone's middle block squared: (D (sB B - beta_mid))^2, sBB = sB * B already rounded
 __device__ __forceinline__ double soc_w2(double D, double sBB, double bm) {
     const double w = D * (sBB - bm);
@@ -59,9 +63,20 @@ __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double s
     const bool own1 = t + 1 < d.nl;      // node t + 1 is held here (always on one GPU)
     double acc0 = 0.0, acc1 = 0.0;
     if (CARRIED) {
-        for (int j = j0; j < j1; ++j) {
-            acc0 += d.cn_sq[((int64_t)(2 * j) << d.tp_shift) + t];
-            acc1 += d.cn_sq[((int64_t)(2 * j + 1) << d.tp_shift) + t];
+        for (int j = j0; j < j1; j += CARRY_BATCH) {
+            double q0[CARRY_BATCH], q1[CARRY_BATCH];
+#pragma unroll
+            for (int i = 0; i < CARRY_BATCH; ++i) {
+                const int64_t row = ((int64_t)(2 * min(j + i, j1 - 1)) << d.tp_shift) + t;
+                q0[i] = d.cn_sq[row];
+                q1[i] = d.cn_sq[row + d.TP];
+            }
+#pragma unroll
+            for (int i = 0; i < CARRY_BATCH; ++i) {
+                if (j + i >= j1) break;
+                acc0 += q0[i];
+                acc1 += q1[i];
+            }
         }
     } else {
         for (int j = j0; j < j1; ++j) {
@@ -122,14 +137,24 @@ __device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double 
     const bool two = t + 1 < d.ni;                 // the second interval exists (T odd: not for the last pair)
     const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
     double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
-    if (CARRIED) {
-        const double *__restrict__ q = d.cn_sq + ((int64_t)(2 * j0) << d.tp_shift) + t;
-        for (int j = j0; j < j1; ++j, q += 2 * d.TP) {
-            const D2 q0 = ld2(q), q1 = ld2(q + d.TP);
-            a0[0] += q0.v[0];
-            a1[0] += q1.v[0];
-            a0[1] += q0.v[1];
-            a1[1] += q1.v[1];
+    if (CARRIED) {      // CARRY_BATCH corners' loads in flight (rows clamped to the list, sums in list order)
+        const double *__restrict__ q = d.cn_sq + t;
+        for (int j = j0; j < j1; j += CARRY_BATCH) {
+            D2 q0[CARRY_BATCH], q1[CARRY_BATCH];
+#pragma unroll
+            for (int i = 0; i < CARRY_BATCH; ++i) {
+                const int64_t row = (int64_t)(2 * min(j + i, j1 - 1)) << d.tp_shift;
+                q0[i] = ld2(q + row);
+                q1[i] = ld2(q + row + d.TP);
+            }
+#pragma unroll
+            for (int i = 0; i < CARRY_BATCH; ++i) {
+                if (j + i >= j1) break;
+                a0[0] += q0[i].v[0];
+                a1[0] += q1[i].v[0];
+                a0[1] += q0[i].v[1];
+                a1[1] += q1[i].v[1];
+            }
         }
     }
     for (int j = CARRIED ? j1 : j0; j < j1; ++j) {
@@ -293,7 +318,17 @@ __device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r
     double rhs = (xt - xm) * ih;
     double ds = 0.0;
     if (CARRIED) {      // the corners' shares of div_x((B - E) area) were stored by the last steps-2+3 launch (cn_g[j][node])
-        for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) ds += d.cn_g[((int64_t)j << d.tp_shift) + t];
+        const int jc0 = d.cptr[v], jc1 = d.cptr[v + 1];
+        for (int j = jc0; j < jc1; j += CARRY_BATCH) {
+            double gj[CARRY_BATCH];
+#pragma unroll
+            for (int i = 0; i < CARRY_BATCH; ++i) gj[i] = d.cn_g[((int64_t)min(j + i, jc1 - 1) << d.tp_shift) + t];
+#pragma unroll
+            for (int i = 0; i < CARRY_BATCH; ++i) {
+                if (j + i >= jc1) break;
+                ds += gj[i];
+            }
+        }
     } else {
         for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) {
             const int f = d.cidx[j] / 3;
@@ -386,11 +421,17 @@ __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r,
     double ds[2] = {0.0, 0.0};
     const int jc0 = d.cptr[v], jc1 = d.cptr[v + 1];
     if (CARRIED) {
-        const double *__restrict__ g = d.cn_g + ((int64_t)jc0 << d.tp_shift) + t;
-        for (int j = jc0; j < jc1; ++j, g += d.TP) {
-            const D2 gj = ld2(g);
-            ds[0] += gj.v[0];
-            ds[1] += gj.v[1];
+        const double *__restrict__ g = d.cn_g + t;
+        for (int j = jc0; j < jc1; j += CARRY_BATCH) {
+            D2 gj[CARRY_BATCH];
+#pragma unroll
+            for (int i = 0; i < CARRY_BATCH; ++i) gj[i] = ld2(g + ((int64_t)min(j + i, jc1 - 1) << d.tp_shift));
+#pragma unroll
+            for (int i = 0; i < CARRY_BATCH; ++i) {
+                if (j + i >= jc1) break;
+                ds[0] += gj[i].v[0];
+                ds[1] += gj[i].v[1];
+            }
         }
     }
     for (int j = CARRIED ? jc1 : jc0; j < jc1; ++j) {
@@ -1008,6 +1049,9 @@ __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carr
     const int e = 2 * tid, lr = e >> d.tp_shift, t = e & (d.TP - 1);      // local row (3 per triangle), first node
     const int f = wg * tri_per_wg + lr / 3, c = lr - 3 * (lr / 3);
     const bool active = f < d.F && t < d.nl;      // (a whole triangle is active or not; so is a column over its three rows)
+#ifndef DOTS_CARRY_CPOS_LATE
+    const int j = active ? d.cpos[f * 3 + c] : 0; // row of this lane's corner k = c in the carried arrays (loaded with the lane's other constants)
+#endif
     if (active) ql2_lane<ZMODE, false, true>(d, f, c, t, sz * INV_SQRT3, 1.0 + 2.0 * sz * sz, 1.0 + sz * sz, tau, xs + tid);
     __syncthreads();
     const int L = d.TP >> 1;                      // lanes per row
@@ -1022,7 +1066,9 @@ __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carr
     // the row's last lane (t = TP - 2) would need interval TP - 1 >= T, which does not exist.
     const double nxt = __shfl_down(q[2], 1, 64);
     if (!active) return;
+#ifdef DOTS_CARRY_CPOS_LATE
     const int j = d.cpos[f * 3 + c];
+#endif
     st2(d.cn_sq + ((int64_t)(2 * j) << d.tp_shift) + t, D2{{q[0], q[1]}});
     st2(d.cn_sq + ((int64_t)(2 * j + 1) << d.tp_shift) + t, D2{{q[3], t + 2 < d.TP ? nxt : 0.0}});
     st2(d.cn_g + ((int64_t)j << d.tp_shift) + t, D2{{q[4], q[5]}});

@@ -31,6 +31,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what this header declares is exported */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define DOTS_ABI_VERSION 7
 
@@ -454,6 +458,9 @@ int64_t dots_debug_counter(dots_ctx *ctx, int which);
 /* device memory in use by the context, bytes */
 int64_t dots_device_bytes(dots_ctx *ctx);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

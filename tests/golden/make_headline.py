@@ -3,6 +3,8 @@
     python tests/golden/make_headline.py reference sphere10k knot knot63     # the REFERENCE itself (via ref_shim)
     python tests/golden/make_headline.py oracle torus100k                    # the CPU oracle (the reference would
                                                                               # need hours at this size)
+    python tests/golden/make_headline.py reference torus100k_ref10 torus65k_T127   # the reference, first 10 iterations
+    python tests/golden/make_headline.py --verify reference knot knot63      # regenerate into a temp dir, compare bit for bit
 
 Geometry comes from dots_socp_amd/meshes.py (deterministic generators), so a fixture stores
 only a checksum of it, the stopping iteration, the cost / objective / KKT histories and a sample of the solution
@@ -36,8 +38,29 @@ WORKLOADS = {   # same table as bench.py
 }
 
 
+def same_fixture(a, b):
+    """Two fixture files hold the same recorded run: every array bit for bit, the wall-clock `seconds` aside."""
+    if set(a.files) != set(b.files):
+        return False, f"keys differ: {sorted(set(a.files) ^ set(b.files))}"
+    for k in a.files:
+        if k == "seconds":
+            continue
+        if a[k].shape != b[k].shape or not np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"):
+            return False, f"{k} differs"
+    return True, "identical"
+
+
 def main(argv):
+    # --verify: record into a temporary directory and compare with the committed fixtures instead of overwriting them
+    #   python tests/golden/make_headline.py --verify reference knot knot63      (exit code 1 if any array differs)
+    verify = "--verify" in argv
+    argv = [a for a in argv if a != "--verify"]
     who, names = argv[0], argv[1:]
+    out_dir = HERE
+    if verify:
+        import tempfile
+
+        out_dir = tempfile.mkdtemp(prefix="headline_verify_")
     if who == "reference":
         import ref_shim
         from make_golden import run_reference
@@ -52,6 +75,7 @@ def main(argv):
         sys.modules["dots_oracle"] = O
         spec.loader.exec_module(O)
         solve = lambda T, g, **kw: O.solver_socp(T, g, **kw)              # noqa: E731
+    failed = False
     for name in names:
         wl = WORKLOADS[name]
         geom, scale = meshes.example(wl["example"], **wl["kw"])
@@ -73,9 +97,15 @@ def main(argv):
         )
         for k, val in hist.history.items():
             out["hist_" + k.replace(" ", "_")] = np.asarray(val, dtype=np.float64)
-        np.savez_compressed(os.path.join(HERE, f"headline_{name}.npz"), **out)
-        print("wrote", f"headline_{name}.npz", who, "last iteration", out["last_iteration"], "cost", hist.history["Transportation cost"][-1],
-              "seconds", round(sec, 1), flush=True)
+        np.savez_compressed(os.path.join(out_dir, f"headline_{name}.npz"), **out)
+        print("wrote", os.path.join(out_dir, f"headline_{name}.npz") if verify else f"headline_{name}.npz", who, "last iteration", out["last_iteration"],
+              "cost", hist.history["Transportation cost"][-1], "seconds", round(sec, 1), flush=True)
+        if verify:
+            ok, why = same_fixture(np.load(os.path.join(out_dir, f"headline_{name}.npz")), np.load(os.path.join(HERE, f"headline_{name}.npz")))
+            print("verify", name, "OK" if ok else "MISMATCH", why, flush=True)
+            failed = failed or not ok
+    if verify and failed:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

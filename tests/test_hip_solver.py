@@ -242,7 +242,7 @@ def test_step_timers_cover_all_iterations():
         assert set(hist.steps_time) == {"Step 1-1 (Laplacian)", "Step 1-2 (SOC-Projection)", "Step 2+3 (Q & Lambda, Multiplier)"}
         sums[every] = sum(hist.steps_time.values())
         assert (hist.steps_time_note is None) == (every == "1")
-        assert sums[every] < 1.15 * hist.running_time      # (an estimate of the device time of the steps; the run is device-bound)
+        assert sums[every] < hist.running_time             # (an estimate of the device time of the steps; the run is device-bound)
     assert abs(sums["32"] - sums["1"]) < 0.15 * sums["1"], sums
     # (b) sphere10k-sized iterations take ~0.2 ms on the device against ~30 us of host work: the loop is device-bound
     geom, _ = meshes.example("sphere", level=5)
@@ -263,7 +263,7 @@ def test_step_timers_cover_all_iterations():
     steps = sum(alm.run_history.steps_time.values()) - t_before
     alm.close()
     # the KKT kernels, the penalty divisions and the host's decisions on read-back iterations are not under a step timer (as in the reference)
-    assert 0.70 * wall < steps < 1.10 * wall, (steps, wall)
+    assert 0.70 * wall < steps < 1.02 * wall, (steps, wall)
 
 
 def test_mailbox_fallback_never_returns_stale_sums():

@@ -34,6 +34,18 @@ def test_library_exports_every_declared_symbol():
     assert lib.dots_abi_version() == _lib.ABI_VERSION
 
 
+def test_library_exports_nothing_but_the_header():
+    """The header is the ABI: the dynamic symbol table of the library holds the declared entry points and nothing else
+    (-fvisibility=hidden + csrc/exports.map; no C++ internals, no kernel stubs)."""
+    import subprocess
+
+    from dots_socp_amd import _lib
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == header_functions()
+
+
 def test_struct_layouts_match_the_header(tmp_path):
     """Compile a probe with gcc against the header and compare sizes/offsets with the ctypes mirror."""
     from dots_socp_amd import _lib
@@ -385,7 +397,9 @@ def test_environment_switches_are_validated(monkeypatch):
 
 
 def test_sampled_step_timers_scale_to_all_iterations():
-    """control.SampledStepTimers: the estimate is (mean of the sampled iterations of a kind) x (iterations of the kind)."""
+    """control.SampledStepTimers: per kind of iteration, the first `first` timed iterations count exactly and the others at the
+    median of the periodic samples; a slow warm-up iteration is NOT scaled to the whole run; records of one iteration that
+    arrive in pieces (time-slab stages) are one sample."""
     from dots_socp_amd.control import RunningHistory, SampledStepTimers, KKT_LABELS, KKT_SHORT_LABELS
 
     hist = RunningHistory(max_record_numbers=10, kkt_labels=KKT_LABELS, kkt_short_labels=KKT_SHORT_LABELS, name="t")
@@ -395,12 +409,23 @@ def test_sampled_step_timers_scale_to_all_iterations():
         kind = "read-back" if i % 4 == 0 else "quiet"
         if tm.begin(kind):
             sampled.append((i, kind))
-            tm.add(kind, "a", 2.0 if kind == "quiet" else 5.0)
-            tm.add(kind, "b", 1.0)
+            warm = 40.0 if i < 2 else 0.0                  # the run's first iterations are slow (cold kernels)
+            tm.add(kind, "a", (2.0 if kind == "quiet" else 5.0) + warm)
+            tm.add(kind, "b", 0.25, 0)                     # two stage records ...
+            tm.add(kind, "b", 0.75)                        # ... of one iteration
     tm.publish()
     assert [i for i, _ in sampled] == [0, 1, 2, 4, 6, 13, 16, 19]        # first two of each kind, then every fifth of its kind
-    assert hist.steps_time["a"] == pytest.approx(15 * 2.0 + 5 * 5.0) and hist.steps_time["b"] == pytest.approx(20.0)
-    assert "20 iterations" in hist.steps_time_note and "8 sampled" in hist.steps_time_note
+    # quiet: 15 iterations = 42 + 2 exactly + 13 x median(2, 2); read-back: 5 = 45 + 5 exactly + 3 x median(5, 5)
+    assert hist.steps_time["a"] == pytest.approx(42.0 + 2.0 + 13 * 2.0 + 45.0 + 5.0 + 3 * 5.0)
+    assert hist.steps_time["b"] == pytest.approx(20.0)
+    assert "20 iterations" in hist.steps_time_note and "8 timed" in hist.steps_time_note
+    # before the first periodic sample the latest timed iteration stands in for the rest (not the warm-up mean)
+    early = SampledStepTimers(hist, first=2, every=50)
+    for i in range(10):
+        if early.begin("quiet"):
+            early.add("quiet", "a", 40.0 if i == 0 else 2.0)
+    early.publish()
+    assert hist.steps_time["a"] == pytest.approx(40.0 + 2.0 + 8 * 2.0)
     every = SampledStepTimers(hist, first=0, every=1)
     for _ in range(3):
         assert every.begin("quiet")
