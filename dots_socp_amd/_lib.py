@@ -18,7 +18,7 @@ ARRAY_IDS = {
 }
 LAP_SOLVERS = {"spacetime_pcg": 0, "modal_pcg": 1}
 PHASES = {"laplacian": 0, "soc_projection": 1, "q_lambda_mult": 2, "q_lambda": 3}
-STEP_SKIP_Z_MID, STEP_PALM, STEP_RHS_AHEAD, STEP_TIMED, STEP_CARRY = 1, 2, 4, 8, 16
+STEP_SKIP_Z_MID, STEP_PALM, STEP_RHS_AHEAD, STEP_TIMED, STEP_CARRY, STEP_KKT_SUMS = 1, 2, 4, 8, 16, 32
 OPERATORS = {
     "grad_time": 0, "div_time": 1, "grad_space": 2, "div_space": 3, "decouple": 4,
     "decouple_adjoint": 5, "time_avg_adjoint": 6, "laplacian_apply": 7,

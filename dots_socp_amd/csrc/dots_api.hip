@@ -261,6 +261,13 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     if ((rc = dev_alloc(c, &d.partials, npart))) return rc;
     if ((rc = dev_alloc(c, &d.scal, CgScalOffsets::TOTAL))) return rc;
     if ((rc = dev_alloc(c, &d.flags, FLAG_TOTAL))) return rc;
+    if (!sharded && tp >= 4) {      // DOTS_STEP_KKT_SUMS: per-workgroup partial sums of the steps-2+3 launch (carry or tile mapping)
+        const int64_t tw = tp <= 128 ? (2 * 192 / tp) / 3 : 1;
+        c->kkt_fused_cap_v = gv;
+        c->kkt_fused_cap_f = std::max<int64_t>(xcd_grid((int)((F + tw - 1) / tw)), (int64_t)gf * (TILE_ELEMS / (2 * BLOCK)));
+        if ((rc = dev_alloc(c, &c->kkt_fused.part_v, (int64_t)N_VSUMS * c->kkt_fused_cap_v))) return rc;
+        if ((rc = dev_alloc(c, &c->kkt_fused.part_f, (int64_t)N_FSUMS * c->kkt_fused_cap_f))) return rc;
+    }
     c->stage_count = array_count_device(d, DOTS_Z_MID);
     if ((rc = dev_alloc(c, &c->stage, c->stage_count))) return rc;
     DOTS_HIP(hipHostMalloc((void **)&c->h_pinned, sizeof(double) * CgScalOffsets::TOTAL, hipHostMallocDefault));
@@ -318,7 +325,7 @@ static int check(dots_ctx *ctx, bool reads_only = false) {
     if (!ctx) { set_error("null context"); return DOTS_ERR_ARGUMENT; }
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
-    if (!reads_only) ctx->rhs_ahead = ctx->rhs_ahead_armed = ctx->carry_valid = 0;      // (the carried gathers belong to the state steps 2+3 left)
+    if (!reads_only) ctx->rhs_ahead = ctx->rhs_ahead_armed = ctx->carry_valid = ctx->kkt_fused_valid = 0;      // (the carried gathers / fused sums belong to the state steps 2+3 left)
     return 0;
 }
 
@@ -326,7 +333,7 @@ static int check(dots_ctx *ctx, bool reads_only = false) {
 static int palm_step0(Ctx *c) {
     if (!c->step_palm) return 0;
     if (c->zmid_stale) { set_error("step: DOTS_STEP_PALM needs z_mid of the previous iteration in memory"); return DOTS_ERR_STATE; }
-    c->carry_valid = 0;      // step 0 moves A, B and lambda_c
+    c->carry_valid = c->kkt_fused_valid = 0;      // step 0 moves A, B and lambda_c
     return launch_q_lambda_only(c);
 }
 
@@ -717,7 +724,7 @@ int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
 int dots_step_flags(dots_ctx *c, uint32_t flags) {
     int rc = check(c, true);
     if (rc) return rc;
-    if (flags & ~(uint32_t)(DOTS_STEP_SKIP_Z_MID | DOTS_STEP_PALM | DOTS_STEP_RHS_AHEAD | DOTS_STEP_TIMED | DOTS_STEP_CARRY)) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
+    if (flags & ~(uint32_t)(DOTS_STEP_SKIP_Z_MID | DOTS_STEP_PALM | DOTS_STEP_RHS_AHEAD | DOTS_STEP_TIMED | DOTS_STEP_CARRY | DOTS_STEP_KKT_SUMS)) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
     if ((flags & DOTS_STEP_RHS_AHEAD) && (flags & DOTS_STEP_PALM)) { set_error("step_flags: DOTS_STEP_RHS_AHEAD cannot be combined with DOTS_STEP_PALM (its step 0 changes what the right-hand side reads)"); return DOTS_ERR_ARGUMENT; }
     c->rhs_ahead_armed = ((flags & DOTS_STEP_RHS_AHEAD) && rhs_writes_modes(c)) ? 1 : 0;      // (a hint: ignored without the direct solver / on a time slab)
     if ((flags & DOTS_STEP_SKIP_Z_MID) && (flags & DOTS_STEP_PALM)) { set_error("step_flags: DOTS_STEP_PALM reads z_mid, it cannot be combined with DOTS_STEP_SKIP_Z_MID"); return DOTS_ERR_ARGUMENT; }
@@ -725,6 +732,7 @@ int dots_step_flags(dots_ctx *c, uint32_t flags) {
     c->step_palm = (flags & DOTS_STEP_PALM) ? 1 : 0;
     c->step_timed = (flags & DOTS_STEP_TIMED) ? 1 : 0;
     c->step_carry = ((flags & DOTS_STEP_CARRY) && !(flags & DOTS_STEP_PALM)) ? 1 : 0;      // (a hint, like DOTS_STEP_RHS_AHEAD)
+    c->step_kkt = ((flags & DOTS_STEP_KKT_SUMS) && !(flags & DOTS_STEP_SKIP_Z_MID)) ? 1 : 0;  // (a hint as well)
     return 0;
 }
 

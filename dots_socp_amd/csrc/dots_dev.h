@@ -204,6 +204,26 @@ struct CgScalOffsets {
 constexpr int FLAG_ITERS = CgScalOffsets::NCMAX;
 constexpr int FLAG_TOTAL = CgScalOffsets::NCMAX + 8;
 
+// Weighted sums the KKT residuals are combined from (kernels_kkt.hip; solver_socp.py:433-559): vertex sums, then triangle sums
+enum {
+    V_DPHI2 = 0, V_A2, V_LAM2, V_RESMU2, V_RFST2, V_REND2, V_MU2, V_AUX1_2, V_MUAUX1_2,
+    V_COMP_AUX2, V_COMP_RES2, V_CONG_RES2, V_DUALAUX2, N_VSUMS,
+    F_DX2 = N_VSUMS, F_B2, F_RESE2, F_E2, F_AUX2_2, F_EAUX2_2, F_AUX5_2, F_AUX5M_2, F_RMID2, N_SUMS
+};
+constexpr int N_FSUMS = N_SUMS - N_VSUMS;
+static_assert(N_SUMS <= MAX_SUMS, "too many reduction slots");
+struct KktArgs {
+    uint32_t mask;
+    double r, sz, cd, cong, ps, ds, bs;   // penalty, scale_factor_z, constant_d, congestion, prim/dual/boundary scale
+};
+// DOTS_STEP_KKT_SUMS: the sums steps 2+3 can form from their registers while they write the new iterate -- everything the
+// conditions Prim(phi, q), Prim(q, z), Dual(beta) and Comp(rho, cong.) need (no gather across rows): per workgroup partial sums
+struct KktFused {
+    double *part_v = nullptr, *part_f = nullptr;   // [N_VSUMS][nv], [N_FSUMS][nf] (only the fused slots are written)
+    int nv = 0, nf = 0;                            // workgroups of the vertex / triangle part of the launch that wrote them
+};
+constexpr uint32_t KKT_FUSED_MASK = 1u | 2u | 8u | 64u;
+
 struct Ctx;
 bool rhs_on_tiles(const Ctx *c);    // the right-hand-side / projection launch runs on patch tiles (k_rhs_soc_tiles)
 
@@ -305,6 +325,10 @@ struct Ctx {
     int step_timed = 0;           // dots_step_flags
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
     int step_palm = 0;            // dots_step_flags: every iteration opens with the (q, lambda_c) closed form (is_palm = True)
+    int step_kkt = 0;             // dots_step_flags: steps 2+3 also form the KKT sums they hold in registers (kkt_fused)
+    KktFused kkt_fused{};         // their per-workgroup partial sums (own buffer: d.partials serves the other reductions)
+    int64_t kkt_fused_cap_v = 0, kkt_fused_cap_f = 0;   // workgroups the buffers hold per slot
+    int kkt_fused_valid = 0;      // ... and they belong to the current iterate and parameters
     int step_carry = 0;           // dots_step_flags: steps 2+3 also store the next iteration's per-corner gathers (cn_sq, cn_g)
     int carry_valid = 0;          // ... and they belong to the current iterate (cleared by every call that changes state or parameters)
     int zmid_stale = 0;           // z_mid does not belong to the current iterate
@@ -424,7 +448,7 @@ __device__ __forceinline__ double wave_sum(double x) {
 }
 
 // Sum N per-thread values over the workgroup; thread 0 gets the totals.  Fixed order -> deterministic.
-template <int N>
+template <int N, int NW = 4>
 __device__ __forceinline__ void block_sum(double (&v)[N], double *lds /* [N*4] */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -435,7 +459,7 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double *lds /* [N*4] *
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = (lds[i * 4] + lds[i * 4 + 1]) + (lds[i * 4 + 2] + lds[i * 4 + 3]);
+        for (int i = 0; i < N; ++i) v[i] = NW == 4 ? (lds[i * 4] + lds[i * 4 + 1]) + (lds[i * 4 + 2] + lds[i * 4 + 3]) : (lds[i * 4] + lds[i * 4 + 1]) + lds[i * 4 + 2];
     }
 }
 // The same product on the matrix cores (T + 1 >= 64): one v_mfma_f64_16x16x4_f64 per 16 x 16 output tile and 4

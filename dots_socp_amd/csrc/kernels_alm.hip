@@ -657,8 +657,17 @@ int launch_rhs(Ctx *c, bool with_soc) {
 // ------------------------------------------------------------------------------------------
 // QONLY: only the (q, lambda_c) closed form (the reference's "Step 0" of is_palm = True, solver_socp.py:668-672):
 // A, B and lambda_c are written, no multiplier moves.
-template <bool QONLY, int NB = BLOCK>
-__device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, double sz, double cd, double cr, double tau) {
+// The fused KKT sums of the vertex part (DOTS_STEP_KKT_SUMS): the slots of kkt_vertex_body that need nothing beyond this element
+constexpr int KV_N = 10;
+constexpr int KV_SLOT[KV_N] = {V_DPHI2, V_A2, V_LAM2, V_RESMU2, V_RFST2, V_REND2, V_MU2, V_AUX1_2, V_MUAUX1_2, V_CONG_RES2};
+// ... and of the triangle part
+constexpr int KF_N = 7;
+constexpr int KF_SLOT[KF_N] = {F_DX2, F_B2, F_RESE2, F_E2, F_AUX2_2, F_EAUX2_2, F_RMID2};
+
+// KKT: the expressions of kkt_vertex_body (kernels_kkt.hip) on the values this element has just computed, accumulated in ks[KV_N]
+template <bool QONLY, int NB = BLOCK, bool KKT = false>
+__device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, double sz, double cd, double cr, double tau, const KktArgs *ka = nullptr,
+                                                     double *ks = nullptr) {
     const int v0 = tile * d.VT;
     const double a1 = sz * (1.0 + cr);
     const double a2 = 1.0 + 2.0 * sz * a1;
@@ -675,9 +684,27 @@ __device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, dou
         d.A[iv] = a;
         d.lam[iv] = lc;
         if (QONLY) continue;
-        d.mu[iv] = mu + tau * (dphi - a - lc);
-        d.bf[iv] = bf + tau * (zf + sz * a - cd);
-        d.be[iv] = be + tau * (ze - sz * a - cd);
+        const double mun = mu + tau * (dphi - a - lc), bfn = bf + tau * (zf + sz * a - cd), ben = be + tau * (ze - sz * a - cd);
+        d.mu[iv] = mun;
+        d.bf[iv] = bfn;
+        d.be[iv] = ben;
+        if (KKT) {
+            const double m = d.mass_v[v];
+            const double rm = dphi - a - lc;
+            ks[0] += dphi * dphi * m;
+            ks[1] += a * a * m;
+            ks[2] += lc * lc * m;
+            ks[3] += rm * rm * m;
+            const double rf = zf + ka->sz * a - ka->cd, re = ze - ka->sz * a - ka->cd;
+            ks[4] += rf * rf * m;
+            ks[5] += re * re * m;
+            ks[6] += mun * mun * m;
+            const double x1 = ka->sz * (ben - bfn);
+            ks[7] += x1 * x1 * m;
+            ks[8] += (mun + x1) * (mun + x1) * m;
+            const double res = ka->cong * ((ka->ds * ka->r) * mun) - ka->ps * lc;
+            ks[9] += res * res * m;
+        }
     }
 }
 
@@ -778,8 +805,10 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
 // area * hat . (B - E) -- and leaves them in LDS (xl: this lane's column, stride NBX) for the fold over xyz.
 constexpr int CARRY_NB = 192;         // 3 wavefronts: 2 * 192 / TP rows = whole triangles for every pitch <= 128
 constexpr int CARRY_VALUES = 18;      // per lane: 3 corners x (2 halves + 1 divergence share) x 2 nodes
-template <int ZMODE, bool QONLY, bool CARRY>
-__device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, double sB, double diag_in, double diag_bd, double tau, double *xl = nullptr) {
+// KKT: the lane also accumulates the sums of kkt_triangle_body2 that need no gather (ks[KF_N]; sz = scale_factor_z).
+template <int ZMODE, bool QONLY, bool CARRY, bool KKT = false>
+__device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, double sB, double diag_in, double diag_bd, double tau, double *xl = nullptr,
+                                         double sz = 0.0, double *ks = nullptr) {
     const bool two = t + 1 < d.nl;                  // the second node exists (always, unless the slab holds an odd number of nodes)
     const int64_t ie = idxF(d, f, c, t);
     int vk[3];
@@ -792,7 +821,7 @@ __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, doub
         hk[k] = d.hat[(f * 3 + k) * 3 + c];
         Dk[k] = (ZMODE || CARRY) ? d.fk_D[f * 3 + k] : 1.0;
     }
-    const double area = CARRY ? d.area_f[f] : 0.0;
+    const double area = (CARRY || KKT) ? d.area_f[f] : 0.0;
     const bool has1_0 = has_prev_interval(d, t);
     D2 Bold = {{0.0, 0.0}};
     if (ZMODE) Bold = ld2(d.B + ie);
@@ -849,6 +878,33 @@ __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, doub
             // slots whose interval does not exist keep what they hold (zeros): the scalar kernel does not store them either
             n0[k].v[u] = has0 ? bb0[k] + tau * (zz0[k] - sBn) : b0[k].v[u];
             n1[k].v[u] = has1 ? bb1[k] + tau * (zz1[k] - sBn) : b1[k].v[u];
+        }
+        if (KKT && tu < d.nl) {      // kkt_triangle_body2, conditions 0, 3 and the z_mid part of 1, on the values just computed
+            ks[0] += gx * gx * area;
+            ks[1] += bn * bn * area;
+            ks[2] += (gx - bn) * (gx - bn) * area;
+            const double en = En.v[u];
+            ks[3] += en * en * area;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (has0) s0 += n0[k].v[u];
+                if (has1) s1 += n1[k].v[u];
+            }
+            const double x2 = sB * (s0 + s1);
+            ks[4] += x2 * x2 * area;
+            ks[5] += (en + x2) * (en + x2) * area;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (has0) {
+                    const double q = sz * (zz0[k] - sBn);
+                    ks[6] += q * q * area;
+                }
+                if (has1) {
+                    const double q = sz * (zz1[k] - sBn);
+                    ks[6] += q * q * area;
+                }
+            }
         }
         if (CARRY) {      // the expressions of soc_element2 / rhs_value2 on the values those will find in memory
             const bool node = tu < d.nl;
@@ -1031,18 +1087,31 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle2(Dev d, double
 // j = cpos[f * 3 + k]: the rows of a vertex's corners are CONTIGUOUS, so the next right-hand-side / projection launch streams
 // them (soc_element2 / rhs_value2 <CARRIED>) instead of walking index lists into B, E and beta_mid.
 // Replaces one of the three passes over beta_mid per iteration (solver_socp.py:997-1017 reads what :716-722 just wrote).
-#ifdef DOTS_CARRY_WAVES      // A/B: -DDOTS_CARRY_WAVES=4 caps the registers at 128 (20 spilled); default: 148 VGPRs = 3 waves per SIMD
-#define CARRY_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DOTS_CARRY_WAVES)))
-#else
-#define CARRY_OCCUPANCY
+// 148-152 VGPRs = 3 waves per SIMD by themselves; the instantiation with the KKT sums is held there (170 otherwise).
+// (A/B: -DDOTS_CARRY_WAVES=4 caps the registers at 128, 20 spilled: knot 10 900 -> 9 500 it/s, torus100k 630 -> 585)
+#ifndef DOTS_CARRY_WAVES
+#define DOTS_CARRY_WAVES 3
 #endif
-template <int ZMODE>
-__global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carry(Dev d, double sz, double tau, int n_fwg, int tri_per_wg, double cd, double cr) {
+#define CARRY_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DOTS_CARRY_WAVES)))
+// this workgroup's partial sums (thread 0 holds the totals) into the fused-KKT buffers: slot SLOT[i] of block `bid` of `nblk`
+template <int N>
+__device__ __forceinline__ void store_fused(const double (&v)[N], const int (&slot)[N], int first, double *__restrict__ part, int nblk, int bid) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) part[(int64_t)(slot[i] - first) * nblk + bid] = v[i];
+}
+template <int ZMODE, bool KKT = false>
+__global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carry(Dev d, double sz, double tau, int n_fwg, int tri_per_wg, double cd, double cr,
+                                                                                  KktArgs ka, KktFused kf) {
     __shared__ double xs[CARRY_VALUES * CARRY_NB];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= n_fwg) {
-        const int vt = xcd_tile(blockIdx.x - n_fwg, d.n_vtiles);
-        if (vt < d.n_vtiles) q_lambda_vertex_tile<false, CARRY_NB>(d, vt, sz, cd, cr, tau);
+        const int vb = blockIdx.x - n_fwg, vt = xcd_tile(vb, d.n_vtiles);
+        double ks[KV_N] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (vt < d.n_vtiles) q_lambda_vertex_tile<false, CARRY_NB, KKT>(d, vt, sz, cd, cr, tau, &ka, ks);
+        if (KKT) {
+            block_sum<KV_N, CARRY_NB / 64>(ks, xs);
+            if (tid == 0) store_fused<KV_N>(ks, KV_SLOT, 0, kf.part_v, kf.nv, vb);
+        }
         return;
     }
     const int wg = xcd_tile(blockIdx.x, (d.F + tri_per_wg - 1) / tri_per_wg);
@@ -1052,7 +1121,8 @@ __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carr
 #ifndef DOTS_CARRY_CPOS_LATE
     const int j = active ? d.cpos[f * 3 + c] : 0; // row of this lane's corner k = c in the carried arrays (loaded with the lane's other constants)
 #endif
-    if (active) ql2_lane<ZMODE, false, true>(d, f, c, t, sz * INV_SQRT3, 1.0 + 2.0 * sz * sz, 1.0 + sz * sz, tau, xs + tid);
+    double kt[KF_N] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (active) ql2_lane<ZMODE, false, true, KKT>(d, f, c, t, sz * INV_SQRT3, 1.0 + 2.0 * sz * sz, 1.0 + sz * sz, tau, xs + tid, sz, kt);
     __syncthreads();
     const int L = d.TP >> 1;                      // lanes per row
     const int t0 = tid - c * L;                   // the lane of component 0 of this triangle and column
@@ -1065,13 +1135,47 @@ __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carr
     // q[2], q[3]: s = 1 halves of the intervals t - 1 and t.  Stored by interval: (t, t + 1) = (own q[3], the next lane's q[2]);
     // the row's last lane (t = TP - 2) would need interval TP - 1 >= T, which does not exist.
     const double nxt = __shfl_down(q[2], 1, 64);
-    if (!active) return;
+    if (active) {
 #ifdef DOTS_CARRY_CPOS_LATE
-    const int j = d.cpos[f * 3 + c];
+        const int j = d.cpos[f * 3 + c];
 #endif
-    st2(d.cn_sq + ((int64_t)(2 * j) << d.tp_shift) + t, D2{{q[0], q[1]}});
-    st2(d.cn_sq + ((int64_t)(2 * j + 1) << d.tp_shift) + t, D2{{q[3], t + 2 < d.TP ? nxt : 0.0}});
-    st2(d.cn_g + ((int64_t)j << d.tp_shift) + t, D2{{q[4], q[5]}});
+        st2(d.cn_sq + ((int64_t)(2 * j) << d.tp_shift) + t, D2{{q[0], q[1]}});
+        st2(d.cn_sq + ((int64_t)(2 * j + 1) << d.tp_shift) + t, D2{{q[3], t + 2 < d.TP ? nxt : 0.0}});
+        st2(d.cn_g + ((int64_t)j << d.tp_shift) + t, D2{{q[4], q[5]}});
+    }
+    if (KKT) {
+        __syncthreads();      // (the exchange values in xs have been read)
+        block_sum<KF_N, CARRY_NB / 64>(kt, xs);
+        if (tid == 0) store_fused<KF_N>(kt, KF_SLOT, N_VSUMS, kf.part_f, kf.nf, blockIdx.x);
+    }
+}
+
+// Steps 2+3 of an iteration whose residuals are read back but whose successor does NOT start from the state it leaves (a penalty
+// update follows: no carry): the tile mapping of k_q_lambda_mult_triangle2, the lane of ql2_lane, the fused KKT sums.
+template <int ZMODE>
+__global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle2_kkt(Dev d, double sz, double tau, int nf8, double cd, double cr, KktArgs ka, KktFused kf) {
+    __shared__ double lds[(KV_N > KF_N ? KV_N : KF_N) * 4];
+    constexpr int SUB = TILE_ELEMS / (2 * BLOCK);
+    if ((int)blockIdx.x >= nf8 * SUB) {
+        const int vb = blockIdx.x - nf8 * SUB, vt = xcd_tile(vb, d.n_vtiles);
+        double ks[KV_N] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (vt < d.n_vtiles) q_lambda_vertex_tile<false, BLOCK, true>(d, vt, sz, cd, cr, tau, &ka, ks);
+        block_sum<KV_N>(ks, lds);
+        if (threadIdx.x == 0) store_fused<KV_N>(ks, KV_SLOT, 0, kf.part_v, kf.nv, vb);
+        return;
+    }
+    double kt[KF_N] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int tile = xcd_tile(blockIdx.x % nf8, d.n_ftiles);
+    if (tile < d.n_ftiles) {
+        const int e = ((blockIdx.x / nf8) * BLOCK + threadIdx.x) * 2;
+        const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (row < 3 * d.F && t < d.nl) {
+            const int f = row / 3, c = row - 3 * f;
+            ql2_lane<ZMODE, false, false, true>(d, f, c, t, sz * INV_SQRT3, 1.0 + 2.0 * sz * sz, 1.0 + sz * sz, tau, nullptr, sz, kt);
+        }
+    }
+    block_sum<KF_N>(kt, lds);
+    if (threadIdx.x == 0) store_fused<KF_N>(kt, KF_SLOT, N_VSUMS, kf.part_f, kf.nf, blockIdx.x);
 }
 
 // Step 0 of is_palm = True: (A, B, lambda_c) from the current multipliers and the stored z_mid; nothing else moves.
@@ -1088,14 +1192,31 @@ int launch_q_lambda_mult(Ctx *c, int zmid_mode) {
     const dots_params &p = c->prm;
     const int nf8 = xcd_grid(c->d.n_ftiles), nv8 = xcd_grid(c->d.n_vtiles);
     const double cd = p.const_d, cr = p.congestion * p.r;
-    c->carry_valid = 0;
+    c->carry_valid = c->kkt_fused_valid = 0;
+    // DOTS_STEP_KKT_SUMS: the launch also leaves the sums of the KKT conditions it can form from its registers (kkt_fused)
+    const bool kkt = c->step_kkt && zmid_mode >= 1 && c->kkt_fused.part_v && c->ql_two && c->d.TP >= 4 && !c->d.slab;
+    const KktArgs ka{KKT_FUSED_MASK, p.r, p.scale_z, p.const_d, p.congestion, p.prim_scale, p.dual_scale, p.boundary_scale};
+    KktFused kf = c->kkt_fused;
+    kf.nv = nv8;
     if (carry_possible(c) && c->step_carry && zmid_mode >= 1) {      // ... and the next iteration's gathers are formed here (k_q_lambda_mult_carry)
         const int tw = (2 * CARRY_NB / c->d.TP) / 3, n_fwg = xcd_grid((c->d.F + tw - 1) / tw);
         const dim3 g(n_fwg + nv8);
-        if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_carry<2>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr);
-        else hipLaunchKernelGGL((k_q_lambda_mult_carry<1>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr);
+        kf.nf = n_fwg;
+        const bool k = kkt && nv8 <= c->kkt_fused_cap_v && n_fwg <= c->kkt_fused_cap_f;
+        if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_carry<2>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf);
+        else if (k) hipLaunchKernelGGL((k_q_lambda_mult_carry<1, true>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf);
+        else hipLaunchKernelGGL((k_q_lambda_mult_carry<1>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf);
         DOTS_HIP(hipGetLastError());
         c->carry_valid = 1;
+        if (k && zmid_mode == 1) { c->kkt_fused = kf; c->kkt_fused_valid = 1; }
+        return 0;
+    }
+    if (kkt && zmid_mode == 1 && nv8 <= c->kkt_fused_cap_v && nf8 * (TILE_ELEMS / (2 * BLOCK)) <= c->kkt_fused_cap_f) {
+        kf.nf = nf8 * (TILE_ELEMS / (2 * BLOCK));
+        hipLaunchKernelGGL((k_q_lambda_mult_triangle2_kkt<1>), dim3(kf.nf + nv8), dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr, ka, kf);
+        DOTS_HIP(hipGetLastError());
+        c->kkt_fused = kf;
+        c->kkt_fused_valid = 1;
         return 0;
     }
     if (c->ql_two && c->d.TP >= 4) {      // two nodes per lane (16-byte accesses): k_q_lambda_mult_triangle2
@@ -1373,7 +1494,8 @@ void preload_alm_kernels() {
         (const void *)k_q_lambda_mult_triangle<0>, (const void *)k_q_lambda_mult_triangle<1>, (const void *)k_q_lambda_mult_triangle<2>,
         (const void *)k_q_lambda_mult_triangle<0, true>,
         (const void *)k_q_lambda_mult_triangle2<0>, (const void *)k_q_lambda_mult_triangle2<1>, (const void *)k_q_lambda_mult_triangle2<2>,
-        (const void *)k_q_lambda_mult_carry<1>, (const void *)k_q_lambda_mult_carry<2>,
+        (const void *)k_q_lambda_mult_carry<1>, (const void *)k_q_lambda_mult_carry<2>, (const void *)k_q_lambda_mult_carry<1, true>,
+        (const void *)k_q_lambda_mult_triangle2_kkt<1>,
         (const void *)k_divide_five, (const void *)k_scale, (const void *)k_divide, (const void *)k_rebuild_mu, (const void *)k_rebuild_E,
     };
     hipFuncAttributes a;

@@ -15,18 +15,6 @@ namespace dots {
 
 using S = CgScalOffsets;
 
-enum {
-    V_DPHI2 = 0, V_A2, V_LAM2, V_RESMU2, V_RFST2, V_REND2, V_MU2, V_AUX1_2, V_MUAUX1_2,
-    V_COMP_AUX2, V_COMP_RES2, V_CONG_RES2, V_DUALAUX2, N_VSUMS,
-    F_DX2 = N_VSUMS, F_B2, F_RESE2, F_E2, F_AUX2_2, F_EAUX2_2, F_AUX5_2, F_AUX5M_2, F_RMID2, N_SUMS
-};
-constexpr int N_FSUMS = N_SUMS - N_VSUMS;
-static_assert(N_SUMS <= MAX_SUMS, "too many reduction slots");
-
-struct KktArgs {
-    uint32_t mask;
-    double r, sz, cd, cong, ps, ds, bs;   // penalty, scale_factor_z, constant_d, congestion, prim/dual/boundary scale
-};
 
 // One element per thread (a workgroup takes a quarter of a tile, as the cone projection does): the corner walks of
 // Comp(rho, f(q)) and Dual(alpha) are chains of dependent loads, and these kernels run on the iterations whose
@@ -464,13 +452,25 @@ __global__ void k_mail_sums(const double *__restrict__ src, int n, double *mail,
 // The reduction of the KKT sums and their hand-over in one launch: workgroup = slot (vertex slots sum nv partial blocks,
 // triangle slots nf; a part that did not run gives 0); every workgroup writes its sum to scal and to the mailbox, the last one
 // to arrive (device counter) publishes the sequence number.
-__global__ __launch_bounds__(BLOCK) void k_reduce_mail(const double *__restrict__ part_v, int nv, const double *__restrict__ part_f, int nf,
-                                                       double *__restrict__ out, double *mail, double seq, int *counter) {
+// (src: where every slot's per-workgroup partial sums lie and how many there are -- the KKT kernels of this file, or the
+// steps-2+3 launch that formed them from its registers: DOTS_STEP_KKT_SUMS)
+struct ReduceSrc {
+    const double *p[N_SUMS];
+    int n[N_SUMS];
+};
+static ReduceSrc reduce_src(const double *part_v, int nv, const double *part_f, int nf) {
+    ReduceSrc r{};
+    for (int i = 0; i < N_SUMS; ++i) {
+        r.p[i] = i < N_VSUMS ? part_v + (int64_t)i * nv : part_f + (int64_t)(i - N_VSUMS) * nf;
+        r.n[i] = i < N_VSUMS ? nv : nf;
+    }
+    return r;
+}
+__global__ __launch_bounds__(BLOCK) void k_reduce_mail(ReduceSrc src, double *__restrict__ out, double *mail, double seq, int *counter) {
     __shared__ double lds[4];
     const int slot = blockIdx.x;
-    const bool vs = slot < N_VSUMS;
-    const double *__restrict__ part = vs ? part_v + (int64_t)slot * nv : part_f + (int64_t)(slot - N_VSUMS) * nf;
-    const int nblk = vs ? nv : nf;
+    const double *__restrict__ part = src.p[slot];
+    const int nblk = src.n[slot];
     // (four partial sums per thread: at 10^5 vertices a slot has 4 x 10^4 blocks, one chain of loads per thread took 60 us)
     double w[4] = {0.0, 0.0, 0.0, 0.0};
     int g = threadIdx.x;
@@ -551,7 +551,7 @@ int kkt_sums_device(Ctx *c, uint32_t mask, double *out) {
     if (two) hipLaunchKernelGGL(k_kkt_sums<true>, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
     else hipLaunchKernelGGL(k_kkt_sums<false>, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
     // (a part that did not run sums zero blocks: its slots are zero)
-    hipLaunchKernelGGL(k_reduce_mail, dim3(N_SUMS), dim3(BLOCK), 0, c->stream, d.partials, nv, part_f, nf, out, (double *)nullptr, 0.0, (int *)nullptr);
+    hipLaunchKernelGGL(k_reduce_mail, dim3(N_SUMS), dim3(BLOCK), 0, c->stream, reduce_src(d.partials, nv, part_f, nf), out, (double *)nullptr, 0.0, (int *)nullptr);
     DOTS_HIP(hipGetLastError());
     return 0;
 }
@@ -568,15 +568,43 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
     const bool need_v = mask & (1u | 2u | 4u | 8u | 16u | 64u), need_f = mask & (1u | 2u | 8u | 32u);
     for (int i = 0; i < N_SUMS; ++i) sums[i] = 0.0;
     if (d.nl == 0) return 0;          // a rank without nodes contributes nothing
-    const int nv = need_v ? gv : 0, nf = need_f ? gf : 0;
+    int nv = need_v ? gv : 0, nf = need_f ? gf : 0;
     if (nv + nf == 0) return 0;
-    if (two) hipLaunchKernelGGL(k_kkt_sums<true>, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
-    else hipLaunchKernelGGL(k_kkt_sums<false>, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
+    // DOTS_STEP_KKT_SUMS: the last steps-2+3 launch left the sums of Prim(phi, q), Prim(q, z), Dual(beta) and Comp(rho, cong.)
+    // (no pass over the state for them); Dual(alpha) gathers E over the corner lists: the vertex kernel alone, with that
+    // condition only.  Conditions that gather more (4, 5) take the kernels of this file for everything.
+    const bool fused = c->kkt_fused_valid && !(mask & ~(KKT_FUSED_MASK | 4u)) && c->spin_fetch && c->h_mail && c->kkt_counter;
+    ReduceSrc src = reduce_src(d.partials, nv, part_f, nf);
+    bool have[N_SUMS];
+    for (int i = 0; i < N_SUMS; ++i) have[i] = (i < N_VSUMS) ? need_v : need_f;
+    if (fused) {
+        nv = (mask & 4u) ? gv : 0;
+        a.mask = 4u;
+        for (int i = 0; i < N_SUMS; ++i) { src.p[i] = d.partials; src.n[i] = 0; have[i] = false; }
+        src.p[V_DUALAUX2] = d.partials + (int64_t)V_DUALAUX2 * nv;
+        src.n[V_DUALAUX2] = nv;
+        have[V_DUALAUX2] = nv > 0;
+        const KktFused &kf = c->kkt_fused;
+        for (int i = 0; i < N_SUMS; ++i) {
+            const bool v_slot = i == V_DPHI2 || i == V_A2 || i == V_LAM2 || i == V_RESMU2 || i == V_RFST2 || i == V_REND2 || i == V_MU2 || i == V_AUX1_2 ||
+                                i == V_MUAUX1_2 || i == V_CONG_RES2;
+            const bool f_slot = i == F_DX2 || i == F_B2 || i == F_RESE2 || i == F_E2 || i == F_AUX2_2 || i == F_EAUX2_2 || i == F_RMID2;
+            if (v_slot) { src.p[i] = kf.part_v + (int64_t)i * kf.nv; src.n[i] = kf.nv; have[i] = true; }
+            if (f_slot) { src.p[i] = kf.part_f + (int64_t)(i - N_VSUMS) * kf.nf; src.n[i] = kf.nf; have[i] = true; }
+        }
+        if (nv) {
+            if (two) hipLaunchKernelGGL(k_kkt_sums<true>, dim3(nv), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
+            else hipLaunchKernelGGL(k_kkt_sums<false>, dim3(nv), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
+        }
+    } else {
+        if (two) hipLaunchKernelGGL(k_kkt_sums<true>, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
+        else hipLaunchKernelGGL(k_kkt_sums<false>, dim3(nv + nf), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
+    }
     int rc;
     if (c->spin_fetch && c->h_mail && c->kkt_counter) {
         const double seq = (double)(++c->mail_seq);
         const bool drop = c->mail_test_drop > 0 && c->mail_seq % (uint64_t)c->mail_test_drop == 0;      // tests: this publish goes astray
-        hipLaunchKernelGGL(k_reduce_mail, dim3(N_SUMS), dim3(BLOCK), 0, c->stream, d.partials, nv, part_f, nf, c->d.scal + S::SUMS, c->h_mail, drop ? -seq : seq, c->kkt_counter);
+        hipLaunchKernelGGL(k_reduce_mail, dim3(N_SUMS), dim3(BLOCK), 0, c->stream, src, c->d.scal + S::SUMS, c->h_mail, drop ? -seq : seq, c->kkt_counter);
         DOTS_HIP(hipGetLastError());
         // DOTS_STEP_RHS_AHEAD: while the host waits for these sums and decides, the device starts on the next iteration's
         // right-hand side (it reads only what the next dots_step would read; dots_api.hip: check() drops it if anything changes)
@@ -594,7 +622,7 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
     }
     if (rc) return rc;
     // slots of kernels that did not run hold leftovers of earlier calls: report zeros there
-    for (int i = 0; i < N_SUMS; ++i) sums[i] = ((i < N_VSUMS) ? need_v : need_f) ? c->h_pinned[i] : 0.0;
+    for (int i = 0; i < N_SUMS; ++i) sums[i] = have[i] ? c->h_pinned[i] : 0.0;
     return 0;
 }
 

@@ -171,13 +171,14 @@ class DeviceProblem:
         _lib.check(self.lib.dots_step(self._h, int(n_iters), C.byref(st)), "dots_step")
         return st
 
-    def step_flags(self, skip_z_mid=False, palm=False, rhs_ahead=False, timed=False, carry=False):
+    def step_flags(self, skip_z_mid=False, palm=False, rhs_ahead=False, timed=False, carry=False, kkt_sums=False):
         """``rhs_ahead`` (DOTS_STEP_RHS_AHEAD): the first KKT read-back after the next step also enqueues the right-hand side of
         the iteration after it; only meaningful with the direct solver on one GPU.  ``timed`` (DOTS_STEP_TIMED): enqueue-only
         steps record phase events that ``step_times`` collects later.  ``carry`` (DOTS_STEP_CARRY): the next iteration starts
-        from the state this one leaves, so steps 2+3 also store the per-corner sums its right-hand side and projection gather."""
+        from the state this one leaves, so steps 2+3 also store the per-corner sums its right-hand side and projection gather.
+        ``kkt_sums`` (DOTS_STEP_KKT_SUMS): residuals are read after the step; steps 2+3 also form the sums of conditions 0, 1, 3, 6."""
         flags = ((_lib.STEP_SKIP_Z_MID if skip_z_mid else 0) | (_lib.STEP_PALM if palm else 0) | (_lib.STEP_RHS_AHEAD if rhs_ahead else 0)
-                 | (_lib.STEP_TIMED if timed else 0) | (_lib.STEP_CARRY if carry else 0))
+                 | (_lib.STEP_TIMED if timed else 0) | (_lib.STEP_CARRY if carry else 0) | (_lib.STEP_KKT_SUMS if kkt_sums else 0))
         _lib.check(self.lib.dots_step_flags(self._h, flags), "dots_step_flags")
 
     def step_times(self, wait=False, capacity=64):

@@ -89,6 +89,7 @@ class AlmSolver:
                                                     and np.asarray(geometry["vertices"]).shape[0] * (int(n_time) + 1) <= 200_000)))
         self._rhs_ahead = False
         self._carry = False             # DOTS_STEP_CARRY for the next device step (iterate())
+        self._fused_kkt = False         # the last device step formed the KKT sums it holds in registers (DOTS_STEP_KKT_SUMS)
         if direct and reorder is True:
             reorder = "nd"      # the elimination order of the factor doubles as the locality numbering
         self.dev = dev = DeviceProblem(n_time, geometry, lap_solver="modal_pcg" if direct else lap_solver, device=device,
@@ -264,15 +265,30 @@ class AlmSolver:
     # ---- KKT residuals of the current iterate, evaluated at most once each: the conditions an iteration is known to need
     # (the four primal / dual ones before a penalty update, all seven in step-by-step mode and at the end) are fetched in
     # ONE device call (one pass of the KKT kernels, one host round trip) instead of one call per condition
+    # After a step with DOTS_STEP_KKT_SUMS the conditions FUSED_KKT cost no pass over the state (their sums were formed by steps
+    # 2+3) and Dual(alpha) one vertex pass: whatever of them the lazy validator may ask for next (its queue runs 6, 2, 0, 3, 1)
+    # comes with the first round trip.  Which values the validator LOOKS at -- and so the NaN pattern of the history -- is
+    # unchanged: the cache only holds more than was asked for.  Conditions 4 and 5 gather over corner lists and keep their own pass.
+    FUSED_KKT = (0, 1, 3, 6)
+
+    def _widen(self, conditions):
+        want = set(conditions)
+        if not self._fused_kkt or want & {4, 5}:
+            return list(conditions)
+        if want & {2, 6}:      # (6 passes whenever there is no congestion, and 2 follows it in the queue)
+            want.add(2)
+        want.update(self.FUSED_KKT)
+        return sorted(want - set(self._kkt_cache))
+
     def _kkt_value(self, i):
         if i not in self._kkt_cache:
-            self._kkt_cache.update(self._kkt([i]))
+            self._kkt_cache.update(self._kkt(self._widen([i])))
         return self._kkt_cache[i]
 
     def _kkt_prefetch(self, conditions):
         missing = [i for i in conditions if i not in self._kkt_cache]
         if missing:
-            self._kkt_cache.update(self._kkt(missing))
+            self._kkt_cache.update(self._kkt(self._widen(missing)))
 
     # ---- what the multi-GPU solver overrides: everything that reads numbers or arrays back from the device(s)
     def _kkt(self, conditions):
@@ -302,7 +318,8 @@ class AlmSolver:
         if self.direct:
             timed = sample and len(self._timed_in_flight) < 60       # (the ring of the library holds 64 slots)
             self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, rhs_ahead=self._rhs_ahead and not quiet, timed=timed,
-                                carry=self._carry)
+                                carry=self._carry, kkt_sums=not quiet)
+            self._fused_kkt = not quiet
             self.dev.step(1, wait=False)
             if timed:
                 self._timed_in_flight.append(kind)

@@ -203,6 +203,13 @@ int dots_step(dots_ctx *ctx, int n_iters, dots_step_stats *stats);
  * between that changes the state or the parameters drops them and the step gathers from the arrays again: results never depend
  * on the flag, bit for bit (both paths form the same sums in the same order). */
 #define DOTS_STEP_CARRY 16u
+/* DOTS_STEP_KKT_SUMS (a hint: one GPU, ignored with DOTS_STEP_SKIP_Z_MID): the caller will read KKT residuals after this step.  Steps 2+3
+ * then also accumulate the weighted sums of Prim(phi, q), Prim(q, z), Dual(beta) and Comp(rho, cong.) (solver_socp.py:433-464,
+ * 484-503, 549-559) from the values they hold in registers as they write the new iterate; a following dots_kkt / dots_kkt_sums
+ * whose mask holds only these conditions and Dual(alpha) reduces those partial sums (plus one vertex pass for Dual(alpha))
+ * instead of reading the state again.  Any call in between that changes the state or the parameters drops them.  The residuals
+ * agree with the stand-alone evaluation to rounding (the sums are formed in a different order). */
+#define DOTS_STEP_KKT_SUMS 32u
 int dots_step_flags(dots_ctx *ctx, uint32_t flags);      /* also apply to dots_slab_stage */
 /* The phase times of the timed steps that have finished (wait != 0: of all timed steps, waiting for them), oldest first, at
  * most `capacity`: one dots_step_stats per dots_step iteration (alm_iterations = 1), or one per slab stage (the stage's time in

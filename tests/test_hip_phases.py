@@ -377,6 +377,60 @@ def test_carried_gathers_are_bit_identical_and_dropped_on_changes(fixture, T):
     assert a[1] == b[1] and a[2] == b[2]
 
 
+@pytest.mark.parametrize("fixture,T", [("ops_ico1.npz", None), ("ops_torus8x6.npz", 31), ("ops_refplane4.npz", 64), ("ops_ico1.npz", 127)])
+@pytest.mark.parametrize("congestion", [0.0, 0.05])
+def test_kkt_sums_formed_by_steps_2_and_3(fixture, T, congestion):
+    """DOTS_STEP_KKT_SUMS: steps 2+3 accumulate the sums of Prim(phi, q), Prim(q, z), Dual(beta), Comp(rho, cong.) from their registers;
+    dots_kkt then reduces them (plus one vertex pass for Dual(alpha)) instead of reading the state again.  Same residuals to
+    rounding as the stand-alone kernels, with and without the carry mapping, alone / together / mixed with conditions 4 and 5;
+    the iterate itself does not depend on the flag; a change of state or parameters in between drops the sums."""
+    from dots_socp_amd.device import DeviceProblem
+
+    g = golden(fixture)
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    T = int(g["n_time"]) if T is None else T
+
+    def run(fused):
+        dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+        dev.setup_frontal(leaf=4)
+        dev.scale_z(2.0, 0.5, 2.0)
+        dev.set_params(scale_z=2.0, const_d=2.0, congestion=congestion)
+        res = []
+        for k in range(8):
+            dev.step_flags(carry=k % 2 == 0, kkt_sums=fused)
+            dev.step(1, wait=False)
+            if k == 0:
+                res += [dev.kkt([i]) for i in (6, 2, 0, 3, 1)]             # one at a time, the validator's order
+            elif k == 1:
+                res.append(dev.kkt([0, 1, 2, 3]))                            # a penalty update's request
+            elif k == 2:
+                res.append(dev.kkt([0, 1, 2, 3, 6]))
+                res.append(dev.kkt(range(7)))                                # conditions 4, 5: the stand-alone kernels for all seven
+            elif k == 3:
+                dev.adjust_penalty(1.3)
+                dev.set_params(r=1.3)
+                res.append(dev.kkt([0, 1, 3, 6]))                            # after a change of state: evaluated from the arrays
+            elif k == 4:
+                res.append(dev.kkt([1]))
+                res.append(dev.kkt([4, 5]))
+                res.append(dev.kkt([3, 6]))
+        out = (dev.download_all(), res)
+        dev.close()
+        return out
+
+    a, b = run(False), run(True)
+    for k in a[0]:
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert len(a[1]) == len(b[1])
+    for x, y in zip(a[1], b[1]):
+        assert x.keys() == y.keys()
+        for i in x:
+            for p, q in zip(x[i], y[i]):
+                assert (p is None) == (q is None)
+                if p is not None:
+                    assert abs(p - q) <= 1e-12 * abs(p) + 1e-300, (i, p, q)
+
+
 def test_carry_flag_is_a_hint():
     """DOTS_STEP_CARRY is ignored without the direct solver and with is_palm's step 0 (which moves B before the right-hand side)."""
     from dots_socp_amd.device import DeviceProblem
