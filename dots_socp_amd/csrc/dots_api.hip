@@ -321,11 +321,21 @@ static int build(Ctx *c, const dots_problem_desc *p) {
 
 // `reads_only`: the entry point changes neither the state nor the parameters.  Every other one drops a right-hand side that was
 // enqueued ahead of its iteration (DOTS_STEP_RHS_AHEAD): the next dots_step then computes it again.
-static int check(dots_ctx *ctx, bool reads_only = false) {
+// A pending penalty division (Ctx::pending_div) carried out now: the stand-alone pass over the five dual arrays.
+static int flush_division(Ctx *c) {
+    if (c->pending_div == 0.0) return 0;
+    const double f = c->pending_div;
+    c->pending_div = 0.0;
+    return launch_adjust_penalty(c, f);
+}
+
+// `keeps_division`: the entry point neither reads nor writes the dual arrays (or, dots_step, applies a pending division itself).
+static int check(dots_ctx *ctx, bool reads_only = false, bool keeps_division = false) {
     if (!ctx) { set_error("null context"); return DOTS_ERR_ARGUMENT; }
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
     if (!reads_only) ctx->rhs_ahead = ctx->rhs_ahead_armed = ctx->carry_valid = ctx->kkt_fused_valid = 0;      // (the carried gathers / fused sums belong to the state steps 2+3 left)
+    if (!keeps_division) return flush_division(ctx);
     return 0;
 }
 
@@ -392,6 +402,15 @@ static int run_iteration_body(Ctx *c, dots_step_stats *st, hipEvent_t *tv) {
     int rc;
 #define MARK(i) do { if (tv) DOTS_HIP(hipEventRecord(tv[i], c->stream)); } while (0)
     MARK(0);
+    // a pending penalty division rides in this iteration's kernels when both of them can apply it; otherwise it is carried out first
+    const int zmode = c->step_skip_zmid ? 2 : 1;
+    double dv = 0.0;
+    if (c->pending_div != 0.0) {
+        if (!st && !c->step_palm && !c->rhs_ahead && rhs_takes_soc(c) && rhs_divides(c) && ql_divides(c, zmode)) {
+            dv = c->pending_div;
+            c->pending_div = 0.0;
+        } else if ((rc = flush_division(c))) return rc;
+    }
     if ((rc = palm_step0(c))) return rc;
     // the right-hand side of this iteration was enqueued behind the KKT kernels of the last one (DOTS_STEP_RHS_AHEAD) and nothing
     // it reads has changed since: start at the solve; the projection then runs with the inverse transform
@@ -400,12 +419,12 @@ static int run_iteration_body(Ctx *c, dots_step_stats *st, hipEvent_t *tv) {
     if (!st) {   // asynchronous: enqueue only (the direct solver needs no host round trip); nothing is timed
         c->zmid_stale = c->step_skip_zmid;
         if (rhs_takes_soc(c) && !ahead) {   // [right-hand side + projection] -> sweeps -> inverse transform -> steps 2+3
-            if ((rc = launch_rhs(c, true))) return rc;
+            if ((rc = launch_rhs(c, true, dv))) return rc;
             MARK(1);
             if ((rc = cg_solve(c, nullptr))) return rc;
             MARK(2);
             MARK(3);      // (no separate projection launch: dots_step_times splits the first phase between ms_rhs and ms_soc)
-            if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
+            if ((rc = launch_q_lambda_mult(c, zmode, dv))) return rc;
             MARK(4);
             MARK(5);      // back to back with 4: what one event costs on the stream, taken off every phase (dots_step_times)
             if (tv) c->tkind[(c->t_head + c->t_count - 1) % Ctx::TIME_SLOTS] = TKIND_FUSED;
@@ -519,6 +538,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
         ok &= env_int("DOTS_KKT_TWO", 0, 1, &c->kkt_two);
         ok &= env_int("DOTS_RHS_TWO", 0, 1, &c->rhs_two);
         ok &= env_int("DOTS_RHS_TILES", 0, 2, &c->rhs_tiles);
+        ok &= env_int("DOTS_LAZY_DIV", 0, 1, &c->lazy_div);        // 0: a penalty update divides the dual arrays at once
         ok &= env_int("DOTS_CARRY", 0, 1, &c->carry_arrays);       // 0: never allocate the carried gathers (DOTS_STEP_CARRY is then ignored)
         ok &= env_int("DOTS_SPIN_FETCH", 0, 1, &c->spin_fetch);
         ok &= env_int("DOTS_FRONT_VEC2", 0, 3, &c->front_vec2);      // 0 never, 1 / 2 wherever the pitch allows (default), 3 only where bandwidth-bound
@@ -564,7 +584,7 @@ int dots_destroy(dots_ctx *c) {
 }
 
 int dots_set_params(dots_ctx *c, const dots_params *p) {
-    int rc = check(c);
+    int rc = check(c, false, true);
     if (rc) return rc;
     if (!p || !(p->r > 0) || !(p->scale_z > 0) || !(p->cg_tol > 0) || p->eps < 0 || !(p->boundary_scale > 0)) { set_error("bad parameters"); return DOTS_ERR_ARGUMENT; }
     c->prm = *p;
@@ -576,7 +596,7 @@ int dots_get_params(dots_ctx *c, dots_params *p) {
     return 0;
 }
 int dots_sync(dots_ctx *c) {
-    int rc = check(c, true);
+    int rc = check(c, true, true);
     if (rc) return rc;
     DOTS_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -695,7 +715,7 @@ int dots_slab_stage(dots_ctx *c, int stage, dots_step_stats *stats) {
 }
 
 int dots_stream_wait(dots_ctx *c, void *other_stream, int ctx_waits) {
-    int rc = check(c);
+    int rc = check(c, false, true);
     if (rc) return rc;
     hipStream_t other = (hipStream_t)other_stream;       // nullptr = the legacy default stream
     if (ctx_waits) {
@@ -709,7 +729,7 @@ int dots_stream_wait(dots_ctx *c, void *other_stream, int ctx_waits) {
 }
 
 int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
-    int rc = check(c, true);      // (run_iteration consumes the flag itself)
+    int rc = check(c, true, true);      // (run_iteration consumes the flags and a pending penalty division itself)
     if (rc) return rc;
     if (n_iters < 0) { set_error("n_iters < 0"); return DOTS_ERR_ARGUMENT; }
     if (c->shard_stride != 0) { set_error("dots_step on a time slab: use dots_slab_stage"); return DOTS_ERR_STATE; }
@@ -722,7 +742,7 @@ int dots_step(dots_ctx *c, int n_iters, dots_step_stats *stats) {
 }
 
 int dots_step_flags(dots_ctx *c, uint32_t flags) {
-    int rc = check(c, true);
+    int rc = check(c, true, true);
     if (rc) return rc;
     if (flags & ~(uint32_t)(DOTS_STEP_SKIP_Z_MID | DOTS_STEP_PALM | DOTS_STEP_RHS_AHEAD | DOTS_STEP_TIMED | DOTS_STEP_CARRY | DOTS_STEP_KKT_SUMS)) { set_error("step_flags: unknown flag"); return DOTS_ERR_ARGUMENT; }
     if ((flags & DOTS_STEP_RHS_AHEAD) && (flags & DOTS_STEP_PALM)) { set_error("step_flags: DOTS_STEP_RHS_AHEAD cannot be combined with DOTS_STEP_PALM (its step 0 changes what the right-hand side reads)"); return DOTS_ERR_ARGUMENT; }
@@ -737,7 +757,7 @@ int dots_step_flags(dots_ctx *c, uint32_t flags) {
 }
 
 int dots_step_times(dots_ctx *c, dots_step_stats *out, int capacity, int wait, int *n_out) {
-    int rc = check(c, true);
+    int rc = check(c, true, true);
     if (rc) return rc;
     if (!out || !n_out || capacity < 0) { set_error("step_times: bad argument"); return DOTS_ERR_ARGUMENT; }
     int n = 0;
@@ -879,10 +899,16 @@ int dots_objective(dots_ctx *c, double *out) {
 }
 
 int dots_adjust_penalty(dots_ctx *c, double factor) {
-    int rc = check(c);
+    int rc = check(c);      // (carries out a division that is still pending)
     if (rc) return rc;
     if (!(factor > 0)) { set_error("factor must be positive"); return DOTS_ERR_ARGUMENT; }
     c->kkt_halo_fresh = 0;
+    // one GPU, direct solver: the next iteration's kernels apply the division as they read (run_iteration); any other access to
+    // the arrays carries it out first (check)
+    if (c->lazy_div && c->shard_stride == 0 && carry_possible(c)) {
+        c->pending_div = factor;
+        return 0;
+    }
     return launch_adjust_penalty(c, factor);
 }
 int dots_scale_z(dots_ctx *c, double z_mul, double beta_mul, double sz_new) {

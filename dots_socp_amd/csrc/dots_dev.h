@@ -232,8 +232,10 @@ int launch_soc_projection(Ctx *c, int zmid_mode = 0, bool with_inverse = false);
 void preload_alm_kernels();
 void preload_kkt_kernels();
 void preload_transform_kernels();
-int launch_rhs(Ctx *c, bool with_soc = false);   // with_soc (only when rhs_takes_soc): the cone projection rides in the same launch
-int launch_q_lambda_mult(Ctx *c, int zmid_mode = 0);    // 0: read z_mid; 1: rebuild it from the multiplier and store it; 2: rebuild, do not store
+int launch_rhs(Ctx *c, bool with_soc = false, double dv = 0.0);   // with_soc (only when rhs_takes_soc): the cone projection rides in the same launch; dv != 0 (only when rhs_divides): a pending penalty division is applied to what is read
+bool rhs_divides(const Ctx *c);
+bool ql_divides(const Ctx *c, int zmid_mode);
+int launch_q_lambda_mult(Ctx *c, int zmid_mode = 0, double dv = 0.0);    // 0: read z_mid; 1: rebuild it from the multiplier and store it; 2: rebuild, do not store; dv != 0 (only when ql_divides): the dual arrays are divided as they are read and written back divided
 int launch_q_lambda_only(Ctx *c);                       // the (q, lambda_c) closed form alone (is_palm's step 0): z_mid is read from memory
 int launch_adjust_penalty(Ctx *c, double factor);
 int launch_scale_z(Ctx *c, double z_mul, double beta_mul, double sz_new);
@@ -325,6 +327,11 @@ struct Ctx {
     int step_timed = 0;           // dots_step_flags
     int step_skip_zmid = 0;       // dots_step_flags: steps leave z_mid unspecified (never written, rebuilt on the fly)
     int step_palm = 0;            // dots_step_flags: every iteration opens with the (q, lambda_c) closed form (is_palm = True)
+    // A penalty update (dots_adjust_penalty) is not carried out at once: the next iteration's kernels divide the five dual arrays as
+    // they read them and steps 2+3 write them back divided (one pass over beta_mid saved: solver_socp.py:367-371 is 5 passes in the
+    // reference).  Every other entry point that reads or writes those arrays first carries the division out (flush_division).
+    double pending_div = 0.0;     // 0: none
+    int lazy_div = 1;             // DOTS_LAZY_DIV=0: divide at once (A/B measurements)
     int step_kkt = 0;             // dots_step_flags: steps 2+3 also form the KKT sums they hold in registers (kkt_fused)
     KktFused kkt_fused{};         // their per-workgroup partial sums (own buffer: d.partials serves the other reductions)
     int64_t kkt_fused_cap_v = 0, kkt_fused_cap_f = 0;   // workgroups the buffers hold per slot

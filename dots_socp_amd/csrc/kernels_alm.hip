@@ -55,8 +55,11 @@ __device__ __forceinline__ double soc_half(const Dev &d, int v, int t, int s, do
 
 // CARRIED: the corners' shares of both halves were stored by the last steps-2+3 launch (cn_sq[j][s][interval], in corner-LIST
 // order: a vertex's rows are contiguous): two loads per corner, no index chain, neither B nor beta_mid is touched.
-template <bool ONLY_MULTIPLIER, bool CARRIED = false>
-__device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double sz, double cd) {
+// DIV: a penalty update is pending (Ctx::pending_div): the five dual arrays still hold their values BEFORE the division by
+// `dv` (admm_tools / solver_socp.py:367-371) and every entry is divided as it is read -- the same IEEE division the stand-alone
+// kernel (k_divide_five) performs, so nothing changes bit for bit; steps 2+3 of the same iteration write the arrays back divided.
+template <bool ONLY_MULTIPLIER, bool CARRIED = false, bool DIV = false>
+__device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double sz, double cd, double dv = 1.0) {
     const double sB = sz * INV_SQRT3;
     const int iv = idxV(d, v, t);
     const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
@@ -85,11 +88,11 @@ __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double s
             const double D = d.c_D[j];
             double q[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * d.B[idxF(d, f, c, t)], d.bm[idxM(d, fk, 0, c, t)]);
+            for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * d.B[idxF(d, f, c, t)], DIV ? d.bm[idxM(d, fk, 0, c, t)] / dv : d.bm[idxM(d, fk, 0, c, t)]);
             acc0 += sum3(q[0], q[1], q[2]);
             if (own1) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * d.B[idxF(d, f, c, t + 1)], d.bm[idxM(d, fk, 1, c, t)]);
+                for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * d.B[idxF(d, f, c, t + 1)], DIV ? d.bm[idxM(d, fk, 1, c, t)] / dv : d.bm[idxM(d, fk, 1, c, t)]);
                 acc1 += sum3(q[0], q[1], q[2]);
             }
         }
@@ -97,8 +100,8 @@ __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double s
     }
     const double acc = acc0 + acc1;
     const double a = d.A[iv];
-    const double w_fst = cd - sz * a - d.bf[iv];
-    const double w_end = cd + sz * a - d.be[iv];
+    const double w_fst = cd - sz * a - (DIV ? d.bf[iv] / dv : d.bf[iv]);
+    const double w_end = cd + sz * a - (DIV ? d.be[iv] / dv : d.be[iv]);
     const double nrm = sqrt(acc + w_end * w_end);
     double lam = 0.5 * (1.0 + w_fst / nrm);          // 0/0 -> NaN when the pre-image is 0, as in the reference (:1018)
     if (lam == lam) lam = fmin(fmax(lam, 0.0), 1.0);  // np.clip keeps NaN; fmin/fmax would drop it
@@ -129,9 +132,9 @@ __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double s
 // STAGED: the rows of B come from LDS (`rows`: the tile's distinct triangles, [position][c][ldr]; `c_loc`: the position of a
 // corner-list entry's triangle) instead of from memory (k_rhs_soc_tiles): the same values, the same arithmetic.
 // CARRIED: see soc_element -- one 16-byte load per corner and half (the s = 1 shares are stored in the column of their INTERVAL).
-template <bool STAGED, bool CARRIED = false>
+template <bool STAGED, bool CARRIED = false, bool DIV = false>
 __device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double sz, double cd, const double *rows = nullptr, int ldr = 0,
-                                             const int *__restrict__ c_loc = nullptr) {
+                                             const int *__restrict__ c_loc = nullptr, double dv = 1.0) {
     const double sB = sz * INV_SQRT3;
     const int iv = idxV(d, v, t);
     const bool two = t + 1 < d.ni;                 // the second interval exists (T odd: not for the last pair)
@@ -176,6 +179,12 @@ __device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double 
             m0[c] = ld2(d.bm + idxM(d, fk, 0, c, t));
             m1a[c] = d.bm[idxM(d, fk, 1, c, t)];
             m1b[c] = two ? d.bm[idxM(d, fk, 1, c, t + 1)] : 0.0;
+            if (DIV) {
+                m0[c].v[0] /= dv;
+                m0[c].v[1] /= dv;
+                m1a[c] /= dv;
+                m1b[c] /= dv;
+            }
         }
         double q[3];
 #pragma unroll
@@ -191,7 +200,12 @@ __device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double 
         for (int c = 0; c < 3; ++c) q[c] = soc_w2(D, sB * b2[c], m1b[c]);
         a1[1] += sum3(q[0], q[1], q[2]);
     }
-    const D2 A = ld2(d.A + iv), bf = ld2(d.bf + iv), be = ld2(d.be + iv);
+    const D2 A = ld2(d.A + iv);
+    D2 bf = ld2(d.bf + iv), be = ld2(d.be + iv);
+    if (DIV) {
+        bf.v[0] /= dv; bf.v[1] /= dv;
+        be.v[0] /= dv; be.v[1] /= dv;
+    }
     D2 zf, ze, lm;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -306,14 +320,14 @@ int launch_soc_projection(Ctx *c, int zmid_mode, bool with_inverse) {
 // div_x is a gather over the vertex's corner list (no scatter, no atomics).  Each workgroup also
 // emits the partial sum of b (mean removal for the singular eps = 0 operator).
 // ------------------------------------------------------------------------------------------
-template <bool CARRIED = false>
-__device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r, double eps) {
+template <bool CARRIED = false, bool DIV = false>
+__device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r, double eps, double dv = 1.0) {
     const int iv = idxV(d, v, t);
     const double m = d.mass_v[v];
     const double ih = 1.0 / d.h;
     double xt = 0.0, xm = 0.0;
-    if (t < d.ni) xt = (d.A[iv] + d.lam[iv] - d.mu[iv]) * m;
-    if (t > 0) xm = (d.A[iv - 1] + d.lam[iv - 1] - d.mu[iv - 1]) * m;
+    if (t < d.ni) xt = (d.A[iv] + d.lam[iv] - (DIV ? d.mu[iv] / dv : d.mu[iv])) * m;
+    if (t > 0) xm = (d.A[iv - 1] + d.lam[iv - 1] - (DIV ? d.mu[iv - 1] / dv : d.mu[iv - 1])) * m;
     else if (has_prev_interval(d, t)) xm = d.X_lo[v] * m;      // interval t0 - 1 lives in the previous time slab
     double rhs = (xt - xm) * ih;
     double ds = 0.0;
@@ -336,7 +350,7 @@ __device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int64_t i = idxF(d, f, c, t);
-                g[c] = d.c_gA[j * 3 + c] * (d.B[i] - d.E[i]);
+                g[c] = d.c_gA[j * 3 + c] * (d.B[i] - (DIV ? d.E[i] / dv : d.E[i]));
             }
             ds += sum3(g[0], g[1], g[2]);
         }
@@ -407,14 +421,20 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes(Dev d, double r, double ep
 // The right-hand side at the nodes t and t + 1 (t even) of a vertex by one lane (one GPU), node for node the arithmetic of
 // rhs_value: B and E of both nodes in one 16-byte word per row.
 // STAGED: B - E of the tile's distinct triangles comes from LDS (see soc_element2).
-template <bool STAGED, bool CARRIED = false>
+template <bool STAGED, bool CARRIED = false, bool DIV = false>
 __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r, double eps, double (&out)[2], const double *rows = nullptr, int ldr = 0,
-                                           const int *__restrict__ c_loc = nullptr) {
+                                           const int *__restrict__ c_loc = nullptr, double dv = 1.0) {
     const int iv = idxV(d, v, t);
     const double m = d.mass_v[v];
     const double ih = 1.0 / d.h;
-    const D2 A = ld2(d.A + iv), L = ld2(d.lam + iv), M = ld2(d.mu + iv), P = ld2(d.phi + iv);
-    const double xp = t > 0 ? (d.A[iv - 1] + d.lam[iv - 1] - d.mu[iv - 1]) * m : 0.0;      // interval t - 1
+    const D2 A = ld2(d.A + iv), L = ld2(d.lam + iv), P = ld2(d.phi + iv);
+    D2 M = ld2(d.mu + iv);
+    double mp = t > 0 ? d.mu[iv - 1] : 0.0;
+    if (DIV) {
+        M.v[0] /= dv; M.v[1] /= dv;
+        mp /= dv;
+    }
+    const double xp = t > 0 ? (d.A[iv - 1] + d.lam[iv - 1] - mp) * m : 0.0;      // interval t - 1
     const double x0 = t < d.ni ? (A.v[0] + L.v[0] - M.v[0]) * m : 0.0;                      // interval t
     const double x1 = t + 1 < d.ni ? (A.v[1] + L.v[1] - M.v[1]) * m : 0.0;                  // interval t + 1
     double rhs[2] = {(x0 - xp) * ih, (x1 - x0) * ih};
@@ -447,6 +467,7 @@ __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r,
                 const int64_t i = idxF(d, f, c, t);
                 b[c] = ld2(d.B + i);
                 e[c] = ld2(d.E + i);
+                if (DIV) { e[c].v[0] /= dv; e[c].v[1] /= dv; }
             }
         }
         double g0[3], g1[3];
@@ -470,16 +491,16 @@ __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r,
 
 // k_rhs_modes with two time columns per lane (one GPU, direct solver): 512 threads per tile.
 constexpr int RHS_NB2 = RHS_NB / 2;
-template <bool CARRIED>
+template <bool CARRIED, bool DIV = false>
 __global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double eps, double *__restrict__ bhat, int IC, int n_rhs, double sz, double cd,
-                                                        const int *__restrict__ tile_vertex) {
+                                                        const int *__restrict__ tile_vertex, double dv) {
     // tile_vertex (or null): the tiles' vertices taken from dots_problem_desc.patch_order instead of from the numbering
     const int e = 2 * threadIdx.x, vl = e >> d.tp_shift, t = e & (d.TP - 1);
     if ((int)blockIdx.x >= n_rhs) {
         const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
         if (st >= d.n_vtiles) return;
         const int v = tile_vertex ? tile_vertex[st * d.VT + vl] : (st * d.VT + vl < d.V ? st * d.VT + vl : -1);
-        if (v >= 0 && t < d.ni) soc_element2<false, CARRIED>(d, v, t, sz, cd);
+        if (v >= 0 && t < d.ni) soc_element2<false, CARRIED, DIV>(d, v, t, sz, cd, nullptr, 0, nullptr, dv);
         return;
     }
     extern __shared__ double tm_lds[];
@@ -495,7 +516,7 @@ __global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double 
         const int vv = ee >> d.tp_shift, tt = ee & (TP - 1);
         const int v = tv ? tv[vv] : (v0 + vv < d.V ? v0 + vv : -1);
         double b[2] = {0.0, 0.0};
-        if (v >= 0 && tt < n) rhs_value2<false, CARRIED>(d, v, tt, r, eps, b);
+        if (v >= 0 && tt < n) rhs_value2<false, CARRIED, DIV>(d, v, tt, r, eps, b, nullptr, 0, nullptr, dv);
         xs[vv * TPp + tt] = b[0];
         xs[vv * TPp + tt + 1] = tt + 1 < n ? b[1] : 0.0;
     }
@@ -561,13 +582,13 @@ __global__ __launch_bounds__(TILE2_NB) void k_rhs_soc_tiles(Dev d, TileDev tl, d
 }
 
 // T + 1 >= 64: 32 vertices per workgroup, the transform on the matrix cores.
-template <bool CARRIED>
-__global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, double eps, double *__restrict__ bhat, int n_rhs, int n_tiles, double sz, double cd) {
+template <bool CARRIED, bool DIV = false>
+__global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, double eps, double *__restrict__ bhat, int n_rhs, int n_tiles, double sz, double cd, double dv) {
     if ((int)blockIdx.x >= n_rhs) {      // riders: the cone projection of a tile, as in k_rhs_modes
         const int st = xcd_tile(blockIdx.x - n_rhs, d.n_vtiles);
         if (st >= d.n_vtiles) return;
         const int e = threadIdx.x, v = st * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (v < d.V && t < d.ni) soc_element<true, CARRIED>(d, v, t, sz, cd);
+        if (v < d.V && t < d.ni) soc_element<true, CARRIED, DIV>(d, v, t, sz, cd, dv);
         return;
     }
     extern __shared__ double xs_m[];                    // [TM_ROWS][TP + 1]
@@ -577,7 +598,7 @@ __global__ __launch_bounds__(RHS_NB) void k_rhs_modes_mfma(Dev d, double r, doub
     const int v0 = tile * TM_ROWS;
     for (int e = threadIdx.x; e < TM_ROWS * TP; e += RHS_NB) {
         const int vl = e >> d.tp_shift, t = e & (TP - 1);
-        xs_m[vl * TPp + t] = (v0 + vl < d.V && t < n) ? rhs_value<CARRIED>(d, v0 + vl, t, r, eps) : 0.0;
+        xs_m[vl * TPp + t] = (v0 + vl < d.V && t < n) ? rhs_value<CARRIED, DIV>(d, v0 + vl, t, r, eps, dv) : 0.0;
     }
     __syncthreads();
     modes_from_tile_mfma<RHS_NB / 64>(d, d.Qpad, xs_m, v0, bhat);
@@ -598,20 +619,33 @@ bool rhs_on_tiles(const Ctx *c) {
     return c->rhs_tiles == 1 && tl.n_tiles > 0 && rhs_tiles_lds(c->d, tl) <= RHS_TILES_LDS_MAX;
 }
 
-int launch_rhs(Ctx *c, bool with_soc) {
+// the right-hand-side (+ projection) launch that launch_rhs would pick can divide the dual arrays as it reads them
+bool rhs_divides(const Ctx *c) {
+    if (!rhs_writes_modes(c) || c->carry_valid) return false;
+    if (time_modes_mfma_ok(c->d)) return true;
+    return c->rhs_two && c->d.TP >= 4 && !rhs_on_tiles(c);
+}
+
+int launch_rhs(Ctx *c, bool with_soc, double dv) {
     const int g = xcd_grid(c->d.n_vtiles);
     if (rhs_writes_modes(c) && time_modes_mfma_ok(c->d)) {      // (two time columns per lane measured here too: knot63 -1.5 %, torus65k_T127 +1.5 %: not kept)
         const int n_tiles = (c->d.V + TM_ROWS - 1) / TM_ROWS, n_rhs = xcd_grid(n_tiles);
         if (c->carry_valid)
             hipLaunchKernelGGL(k_rhs_modes_mfma<true>, dim3(n_rhs + (with_soc ? g : 0)), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
-                               c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, n_tiles, c->prm.scale_z, c->prm.const_d);
+                               c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, n_tiles, c->prm.scale_z, c->prm.const_d, 1.0);
+        else if (dv != 0.0)
+            hipLaunchKernelGGL((k_rhs_modes_mfma<false, true>), dim3(n_rhs + (with_soc ? g : 0)), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
+                               c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, n_tiles, c->prm.scale_z, c->prm.const_d, dv);
         else
             hipLaunchKernelGGL(k_rhs_modes_mfma<false>, dim3(n_rhs + (with_soc ? g : 0)), dim3(RHS_NB), sizeof(double) * TM_ROWS * (c->d.TP + 1), c->stream, c->d,
-                               c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, n_tiles, c->prm.scale_z, c->prm.const_d);
+                               c->prm.r / c->prm.boundary_scale, c->prm.eps, c->d.cg_p0, n_rhs, n_tiles, c->prm.scale_z, c->prm.const_d, 1.0);
     }
     else if (rhs_writes_modes(c) && c->rhs_two && c->d.TP >= 4 && c->carry_valid)      // the corners' shares come from the last steps-2+3 launch
         hipLaunchKernelGGL(k_rhs_modes2<true>, dim3(with_soc ? 2 * g : g), dim3(RHS_NB2), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
-                           c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d, (const int *)nullptr);
+                           c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d, (const int *)nullptr, 1.0);
+    else if (dv != 0.0)      // a penalty update is pending: the dual arrays are divided as they are read (rhs_divides told the caller this launch can)
+        hipLaunchKernelGGL((k_rhs_modes2<false, true>), dim3(with_soc ? 2 * g : g), dim3(RHS_NB2), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
+                           c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d, (const int *)nullptr, dv);
     else if (rhs_writes_modes(c) && c->rhs_two && rhs_on_tiles(c)) {     // patch tiles, triangle rows staged in LDS (large meshes)
         const TileDev &tl = c->tiles;
         const int IC = time_modes_chunk(c->d), gt = xcd_grid(tl.n_tiles);
@@ -630,7 +664,7 @@ int launch_rhs(Ctx *c, bool with_soc) {
     else if (rhs_writes_modes(c) && c->rhs_two && c->d.TP >= 4)      // two time columns per lane (16-byte accesses)
         hipLaunchKernelGGL(k_rhs_modes2<false>, dim3(with_soc ? 2 * g : g), dim3(RHS_NB2), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
                            c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d,
-                           (c->rhs_tiles == 2 && c->tiles.n_tiles > 0) ? c->tiles.vertex : (const int *)nullptr);
+                           (c->rhs_tiles == 2 && c->tiles.n_tiles > 0) ? c->tiles.vertex : (const int *)nullptr, 1.0);
     else if (rhs_writes_modes(c))
         hipLaunchKernelGGL(k_rhs_modes, dim3(with_soc ? 2 * g : g), dim3(RHS_NB), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
                            c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d);
@@ -665,9 +699,9 @@ constexpr int KF_N = 7;
 constexpr int KF_SLOT[KF_N] = {F_DX2, F_B2, F_RESE2, F_E2, F_AUX2_2, F_EAUX2_2, F_RMID2};
 
 // KKT: the expressions of kkt_vertex_body (kernels_kkt.hip) on the values this element has just computed, accumulated in ks[KV_N]
-template <bool QONLY, int NB = BLOCK, bool KKT = false>
+template <bool QONLY, int NB = BLOCK, bool KKT = false, bool DIV = false>
 __device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, double sz, double cd, double cr, double tau, const KktArgs *ka = nullptr,
-                                                     double *ks = nullptr) {
+                                                     double *ks = nullptr, double dv = 1.0) {
     const int v0 = tile * d.VT;
     const double a1 = sz * (1.0 + cr);
     const double a2 = 1.0 + 2.0 * sz * a1;
@@ -677,7 +711,9 @@ __device__ __forceinline__ void q_lambda_vertex_tile(const Dev &d, int tile, dou
         if (v >= d.V || t >= d.ni) continue;
         const int iv = idxV(d, v, t);
         const double dphi = (next_node(d, d.phi, d.phi_hi, v, t) - d.phi[iv]) * ih;
-        const double mu = d.mu[iv], zf = d.zf[iv], ze = d.ze[iv], bf = d.bf[iv], be = d.be[iv];
+        const double zf = d.zf[iv], ze = d.ze[iv];
+        double mu = d.mu[iv], bf = d.bf[iv], be = d.be[iv];
+        if (DIV) { mu /= dv; bf /= dv; be /= dv; }      // (a pending penalty update: see soc_element)
         const double memo = dphi + mu;
         const double a = ia2 * memo + a12 * (ze + be - zf - bf);
         const double lc = cl * (memo - a);
@@ -806,9 +842,9 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
 constexpr int CARRY_NB = 192;         // 3 wavefronts: 2 * 192 / TP rows = whole triangles for every pitch <= 128
 constexpr int CARRY_VALUES = 18;      // per lane: 3 corners x (2 halves + 1 divergence share) x 2 nodes
 // KKT: the lane also accumulates the sums of kkt_triangle_body2 that need no gather (ks[KF_N]; sz = scale_factor_z).
-template <int ZMODE, bool QONLY, bool CARRY, bool KKT = false>
+template <int ZMODE, bool QONLY, bool CARRY, bool KKT = false, bool DIV = false>
 __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, double sB, double diag_in, double diag_bd, double tau, double *xl = nullptr,
-                                         double sz = 0.0, double *ks = nullptr) {
+                                         double sz = 0.0, double *ks = nullptr, double dv = 1.0) {
     const bool two = t + 1 < d.nl;                  // the second node exists (always, unless the slab holds an odd number of nodes)
     const int64_t ie = idxF(d, f, c, t);
     int vk[3];
@@ -830,6 +866,10 @@ __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, doub
         phik[k] = ld2(d.phi + idxV(d, vk[k], t));
         b0[k] = ld2(d.bm + idxM(d, f * 3 + k, 0, c, t));
         b1[k] = ld2(d.bm + idxM(d, f * 3 + k, 1, c, t - 1));
+        if (DIV) {      // (a pending penalty update: see soc_element)
+            b0[k].v[0] /= dv; b0[k].v[1] /= dv;
+            b1[k].v[0] /= dv; b1[k].v[1] /= dv;
+        }
         if (ZMODE) {
             l0[k] = ld2(d.lamc + idxV(d, vk[k], t));
             const double *pl = t > 0 ? d.lamc + idxV(d, vk[k], t - 1) : (has1_0 ? d.lamc_lo + vk[k] : d.lamc + idxV(d, vk[k], t));
@@ -839,7 +879,8 @@ __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, doub
             z1[k] = ld2(d.zm + idxM(d, f * 3 + k, 1, c, t - 1));
         }
     }
-    const D2 Eo = ld2(d.E + ie);
+    D2 Eo = ld2(d.E + ie);
+    if (DIV) { Eo.v[0] /= dv; Eo.v[1] /= dv; }
     D2 Bn, En, n0[3], n1[3];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -1099,15 +1140,15 @@ __device__ __forceinline__ void store_fused(const double (&v)[N], const int (&sl
 #pragma unroll
     for (int i = 0; i < N; ++i) part[(int64_t)(slot[i] - first) * nblk + bid] = v[i];
 }
-template <int ZMODE, bool KKT = false>
+template <int ZMODE, bool KKT = false, bool DIV = false>
 __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carry(Dev d, double sz, double tau, int n_fwg, int tri_per_wg, double cd, double cr,
-                                                                                  KktArgs ka, KktFused kf) {
+                                                                                  KktArgs ka, KktFused kf, double dv) {
     __shared__ double xs[CARRY_VALUES * CARRY_NB];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= n_fwg) {
         const int vb = blockIdx.x - n_fwg, vt = xcd_tile(vb, d.n_vtiles);
         double ks[KV_N] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (vt < d.n_vtiles) q_lambda_vertex_tile<false, CARRY_NB, KKT>(d, vt, sz, cd, cr, tau, &ka, ks);
+        if (vt < d.n_vtiles) q_lambda_vertex_tile<false, CARRY_NB, KKT, DIV>(d, vt, sz, cd, cr, tau, &ka, ks, dv);
         if (KKT) {
             block_sum<KV_N, CARRY_NB / 64>(ks, xs);
             if (tid == 0) store_fused<KV_N>(ks, KV_SLOT, 0, kf.part_v, kf.nv, vb);
@@ -1122,7 +1163,7 @@ __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carr
     const int j = active ? d.cpos[f * 3 + c] : 0; // row of this lane's corner k = c in the carried arrays (loaded with the lane's other constants)
 #endif
     double kt[KF_N] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (active) ql2_lane<ZMODE, false, true, KKT>(d, f, c, t, sz * INV_SQRT3, 1.0 + 2.0 * sz * sz, 1.0 + sz * sz, tau, xs + tid, sz, kt);
+    if (active) ql2_lane<ZMODE, false, true, KKT, DIV>(d, f, c, t, sz * INV_SQRT3, 1.0 + 2.0 * sz * sz, 1.0 + sz * sz, tau, xs + tid, sz, kt, dv);
     __syncthreads();
     const int L = d.TP >> 1;                      // lanes per row
     const int t0 = tid - c * L;                   // the lane of component 0 of this triangle and column
@@ -1188,7 +1229,10 @@ int launch_q_lambda_only(Ctx *c) {
     return 0;
 }
 
-int launch_q_lambda_mult(Ctx *c, int zmid_mode) {
+// steps 2+3 as launch_q_lambda_mult would run them can divide the dual arrays as they read them (the carry kernels)
+bool ql_divides(const Ctx *c, int zmid_mode) { return carry_possible(c) && c->step_carry && zmid_mode >= 1; }
+
+int launch_q_lambda_mult(Ctx *c, int zmid_mode, double dv) {
     const dots_params &p = c->prm;
     const int nf8 = xcd_grid(c->d.n_ftiles), nv8 = xcd_grid(c->d.n_vtiles);
     const double cd = p.const_d, cr = p.congestion * p.r;
@@ -1203,9 +1247,15 @@ int launch_q_lambda_mult(Ctx *c, int zmid_mode) {
         const dim3 g(n_fwg + nv8);
         kf.nf = n_fwg;
         const bool k = kkt && nv8 <= c->kkt_fused_cap_v && n_fwg <= c->kkt_fused_cap_f;
-        if (zmid_mode == 2) hipLaunchKernelGGL((k_q_lambda_mult_carry<2>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf);
-        else if (k) hipLaunchKernelGGL((k_q_lambda_mult_carry<1, true>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf);
-        else hipLaunchKernelGGL((k_q_lambda_mult_carry<1>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf);
+#define CARRY_LAUNCH(Z, K)                                                                                                                                     \
+    do {                                                                                                                                                     \
+        if (dv != 0.0) hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, true>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, dv); \
+        else hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, false>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, 1.0);        \
+    } while (0)
+        if (zmid_mode == 2) CARRY_LAUNCH(2, false);
+        else if (k) CARRY_LAUNCH(1, true);
+        else CARRY_LAUNCH(1, false);
+#undef CARRY_LAUNCH
         DOTS_HIP(hipGetLastError());
         c->carry_valid = 1;
         if (k && zmid_mode == 1) { c->kkt_fused = kf; c->kkt_fused_valid = 1; }
@@ -1489,12 +1539,13 @@ int launch_operator(Ctx *c, int op, double scale, const double *in, double *out)
 void preload_alm_kernels() {
     const void *fns[] = {
         (const void *)k_rhs, (const void *)k_rhs_modes, (const void *)k_rhs_modes2<false>, (const void *)k_rhs_modes2<true>,
-        (const void *)k_rhs_modes_mfma<false>, (const void *)k_rhs_modes_mfma<true>,
+        (const void *)k_rhs_modes_mfma<false>, (const void *)k_rhs_modes_mfma<true>, (const void *)k_rhs_modes_mfma<false, true>, (const void *)k_rhs_modes2<false, true>,
         (const void *)k_soc_projection<true>, (const void *)k_soc_projection<false>, (const void *)k_soc_projection<true, true>,
         (const void *)k_q_lambda_mult_triangle<0>, (const void *)k_q_lambda_mult_triangle<1>, (const void *)k_q_lambda_mult_triangle<2>,
         (const void *)k_q_lambda_mult_triangle<0, true>,
         (const void *)k_q_lambda_mult_triangle2<0>, (const void *)k_q_lambda_mult_triangle2<1>, (const void *)k_q_lambda_mult_triangle2<2>,
         (const void *)k_q_lambda_mult_carry<1>, (const void *)k_q_lambda_mult_carry<2>, (const void *)k_q_lambda_mult_carry<1, true>,
+        (const void *)k_q_lambda_mult_carry<1, false, true>, (const void *)k_q_lambda_mult_carry<2, false, true>, (const void *)k_q_lambda_mult_carry<1, true, true>,
         (const void *)k_q_lambda_mult_triangle2_kkt<1>,
         (const void *)k_divide_five, (const void *)k_scale, (const void *)k_divide, (const void *)k_rebuild_mu, (const void *)k_rebuild_E,
     };

@@ -431,6 +431,57 @@ def test_kkt_sums_formed_by_steps_2_and_3(fixture, T, congestion):
                     assert abs(p - q) <= 1e-12 * abs(p) + 1e-300, (i, p, q)
 
 
+@pytest.mark.parametrize("fixture,T", [("ops_ico1.npz", None), ("ops_torus8x6.npz", 31), ("ops_refplane4.npz", 63), ("ops_ico1.npz", 128)])
+def test_penalty_division_left_to_the_next_iteration(fixture, T, monkeypatch):
+    """dots_adjust_penalty does not divide the five dual arrays at once (solver_socp.py:367-371): the next iteration's kernels divide
+    as they read and steps 2+3 write the arrays back divided; any other access (residuals, a download, norms, another update, a step
+    whose kernels cannot apply it) carries the division out first.  DOTS_LAZY_DIV=0 divides at once: the same numbers bit for bit."""
+    from dots_socp_amd.device import DeviceProblem
+
+    g = golden(fixture)
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    T = int(g["n_time"]) if T is None else T
+
+    def run(lazy):
+        monkeypatch.setenv("DOTS_LAZY_DIV", lazy)
+        dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+        dev.setup_frontal(leaf=4)
+        dev.scale_z(2.0, 0.5, 2.0)
+        dev.set_params(scale_z=2.0, const_d=2.0, congestion=0.05)
+        res, r = [], 1.0
+        for k in range(14):
+            reads = k % 3 == 2
+            dev.step_flags(skip_z_mid=not reads, carry=k not in (7, 10), kkt_sums=reads)
+            if k == 12:
+                dev.step(1)                                  # the synchronous path carries a pending division out first
+            else:
+                dev.step(1, wait=False)
+            if reads:
+                res.append(dev.kkt([0, 1, 2, 3]))
+            if k in (2, 5, 6, 9, 11):                        # (6: applied by the kernels of a quiet iteration; 9: by a step without carry)
+                f = (1.7, 0.6, 1.3, 2.1, 0.8)[(2, 5, 6, 9, 11).index(k)]
+                r *= f
+                dev.adjust_penalty(f)
+                dev.set_params(r=r)
+                if k == 5:
+                    res.append(dev.kkt([3]))                 # residuals right after the update: the division is carried out for them
+                if k == 11:
+                    dev.adjust_penalty(1.1)                  # two updates in a row
+                    r *= 1.1
+                    dev.set_params(r=r)
+                    res.append(float(np.abs(dev.download("beta_mid")).sum()))
+        dev.step_flags(skip_z_mid=False)
+        dev.step(1)
+        out = (dev.download_all(), dev.kkt(range(7)), res)
+        dev.close()
+        return out
+
+    a, b = run("0"), run("1")
+    for k in a[0]:
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert a[1] == b[1] and a[2] == b[2]
+
+
 def test_carry_flag_is_a_hint():
     """DOTS_STEP_CARRY is ignored without the direct solver and with is_palm's step 0 (which moves B before the right-hand side)."""
     from dots_socp_amd.device import DeviceProblem
