@@ -1152,6 +1152,31 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     if (!identity0) FUP(f0, vmap, vmap0.data(), d.V);
     FUP(f0, bd_vertex, bd_vertex.data(), bd_vertex.size());
     const int64_t all_entries = h->n_entries + merged_entries;
+    {   // Does it fit?  The factor (with the merged blocks) stays; the numeric factorisation needs a copy of the fronts and the
+        // Schur complements beside it; the iteration's carried gathers are allocated behind it (dots_front_setup).  The
+        // reference just factorises (laplacian_inverse_socp.py:34-41); here the caller gets a status it can act on
+        // (the Python driver falls back to the multigrid-PCG) instead of a failed allocation halfway through.
+        int64_t srows = 0;
+        for (const FrontNode &nd : nodes) srows += (int64_t)nd.b * nd.b;
+        const double per = 8.0 * (double)d.TP;
+        const double factor_b = per * (double)all_entries, work_b = h->values ? 0.0 : per * (double)(h->n_entries + srows);
+        const double carry_b = (c->shard_stride == 0 && c->d.TP <= 128 && c->carry_arrays) ? 8.0 * 9.0 * (double)c->d.F * (double)c->d.TP : 0.0;
+        size_t free_b = 0, total_b = 0;
+        DOTS_HIP(hipMemGetInfo(&free_b, &total_b));
+        double budget = 0.97 * (double)free_b;
+        int mb = -1;
+        if (!env_int("DOTS_MEM_BUDGET", 0, 1 << 30, &mb)) return DOTS_ERR_ARGUMENT;      // MB the factor may take, whatever is free (tests)
+        if (mb >= 0) budget = 1048576.0 * mb;
+        if (factor_b + work_b + carry_b > budget) {
+            char buf[512];
+            snprintf(buf, sizeof buf, "front_setup: the factor does not fit: %.3f GB (factor %.3f GB for %d modes of %d vertices, %.3f GB while it is "
+                     "computed, %.3f GB of per-corner sums) against %.3f GB available", (factor_b + work_b + carry_b) * 1e-9, factor_b * 1e-9, h->n_modes, d.V,
+                     work_b * 1e-9, carry_b * 1e-9, budget * 1e-9);
+            front_release(c);
+            set_error(buf);
+            return DOTS_ERR_MEMORY;
+        }
+    }
     const double *Fall = nullptr;
     if ((rc = front_upload<double>(c, &Fall, nullptr, all_entries << d.tp_shift))) { front_release(c); return rc; }
     if (h->values) {

@@ -27,6 +27,7 @@ import numpy as np
 
 from ..control import (AdaptiveValidator, AdjustAdmmParam, ConditionValidator, ErrorCondition, RunningHistory, SampledStepTimers,
                        KKT_LABELS, KKT_SHORT_LABELS, max_of_list_with_none, safe_rescale_ratio)
+from .. import _lib
 from .._lib import env_choice
 from ..device import DeviceProblem, STATE_NAMES
 
@@ -108,8 +109,22 @@ class AlmSolver:
         if preconditioner not in ("multigrid", "jacobi"):
             raise ValueError("preconditioner must be 'multigrid' or 'jacobi'")
         self.mg_summary = self.front_summary = None
+        self.lap_solver_fallback = None      # why the direct solve was not used although it was asked for
         if direct:
-            self.front_summary = dev.setup_frontal(eps=self.eps)
+            # Memory regime: the factor holds ~70 entries per vertex and time mode (8.9 GB at 500k vertices x 32 modes).  When it
+            # does not fit beside the state, step 1 runs the batched multigrid-PCG on the same modes instead -- the reference has
+            # no counterpart (laplacian_inverse_socp.py:34-41 just factorises); the choice is logged and reported in solver_stats.
+            try:
+                self.front_summary = dev.setup_frontal(eps=self.eps)
+            except _lib.HipLibraryError as exc:
+                if exc.status != _lib.ERR_MEMORY or time_slab is not None:
+                    raise
+                self.lap_solver_fallback = str(exc)
+                logger.warning("modal_direct -> modal_pcg with the multigrid preconditioner: %s", exc)
+                self.direct = direct = False
+                self._rhs_ahead_ok = False
+                if preconditioner == "multigrid":
+                    self.mg_summary = dev.setup_multigrid(eps=self.eps, coarsest=mg_coarsest)
         elif preconditioner == "multigrid" and lap_solver == "modal_pcg":
             self.mg_summary = dev.setup_multigrid(eps=self.eps, coarsest=mg_coarsest)
         init_solution = init_solution or {}
@@ -454,6 +469,8 @@ class AlmSolver:
             "cg_iterations": int(self.cg_total), "cg_not_converged": int(self.cg_fail), "lap_solver": dev.lap_solver,
             "device_bytes": dev.device_bytes(), "final_r": self.r, "final_scale_z": self.scale_z,
         }
+        if self.lap_solver_fallback:
+            hist.solver_stats.update(lap_solver="modal_pcg (asked for modal_direct)", lap_solver_fallback=self.lap_solver_fallback)
         if self.cg_fail:
             logger.warning("PCG hit its iteration cap in %d solves", self.cg_fail)
         solution = {}

@@ -46,7 +46,8 @@ enum dots_status {
     DOTS_ERR_HIP = -2,
     DOTS_ERR_NO_DEVICE = -3,
     DOTS_ERR_NOT_CONVERGED = -4,
-    DOTS_ERR_STATE = -5
+    DOTS_ERR_STATE = -5,
+    DOTS_ERR_MEMORY = -6      /* dots_front_setup: the factor (+ its workspace) does not fit the device memory that is free */
 };
 
 /* state arrays, same names as SolutionSocpData (dot_surface_socp/utils/type.py:22-38) */
@@ -405,6 +406,9 @@ typedef struct dots_front_desc {
                                     pays on small meshes, where the top band is a few hundred rows) */
 } dots_front_desc;
 
+/* DOTS_ERR_MEMORY (nothing allocated, the context stays usable with the PCG): the factor, the copy of the fronts and the Schur
+ * complements the numeric factorisation needs beside it, and the per-corner sums of DOTS_STEP_CARRY exceed the free device memory
+ * (hipMemGetInfo; DOTS_MEM_BUDGET=<MB> overrides what counts as available).  dots_last_error() names the sizes. */
 int dots_front_setup(dots_ctx *ctx, const dots_front_desc *desc);
 
 /* Host-side helpers for dots_front_desc (no device work; the Python reference implementations are in

@@ -266,6 +266,41 @@ def test_step_timers_cover_all_iterations():
     assert 0.70 * wall < steps < 1.02 * wall, (steps, wall)
 
 
+def test_factor_that_does_not_fit_falls_back_to_the_multigrid_pcg(monkeypatch, caplog):
+    """Memory-regime policy: when the factor, its workspace and the carried sums exceed the device memory that is
+    available (here: DOTS_MEM_BUDGET = 1 MB), dots_front_setup says so with DOTS_ERR_MEMORY -- nothing allocated, the context stays
+    usable -- and lap_solver="modal_direct" runs the batched multigrid-PCG instead, with the reason logged and reported: the run
+    is the reference's run all the same (same stopping iteration, KKT / cost within 1e-6)."""
+    import logging
+
+    from dots_socp_amd import _lib
+    from dots_socp_amd.device import DeviceProblem
+    from dots_socp_amd.socp import solver_socp
+
+    g = golden("run_ico2_T15_cong_tol1e-3.npz")
+    kw = {k[3:]: (g[k].tolist() if g[k].ndim else g[k].item()) for k in g.files if k.startswith("kw_")}
+    monkeypatch.setenv("DOTS_MEM_BUDGET", "1")
+    dev = DeviceProblem(int(g["n_time"]), geom_of(g), lap_solver="modal_pcg")
+    with pytest.raises(_lib.HipLibraryError, match="does not fit") as err:
+        dev.setup_frontal()
+    assert err.value.status == _lib.ERR_MEMORY
+    dev.set_params(cg_tol=1e-10)
+    dev.step(1)                                            # the PCG of the same context still works
+    assert np.isfinite(dev.kkt([0])[0][0])
+    dev.close()
+    with caplog.at_level(logging.WARNING, logger="dots_socp_amd"):
+        sol, hist = solver_socp(int(g["n_time"]), geom_of(g), **kw)
+    assert any("does not fit" in r.getMessage() for r in caplog.records)
+    assert "does not fit" in hist.solver_stats["lap_solver_fallback"] and hist.solver_stats["cg_iterations"] > 0
+    assert int(hist.kkt_iteration[-1]) == int(g["last_iteration"])
+    want, got = g["hist_kkt_errors"], hist.kkt_errors
+    m = ~np.isnan(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.allclose(got[m], want[m], rtol=1e-6, atol=1e-13)
+    monkeypatch.setenv("DOTS_MEM_BUDGET", "100000")
+    _, hist2 = solver_socp(int(g["n_time"]), geom_of(g), **kw)
+    assert "lap_solver_fallback" not in hist2.solver_stats and hist2.solver_stats["cg_iterations"] == 0
+
+
 def test_mailbox_fallback_never_returns_stale_sums():
     """when the mailbox's sequence number does not arrive (here: every third hand-over is published with a wrong
     number, and the spin is cut short), the sums are taken from the device scalars after a stream synchronisation -- the run is
