@@ -679,7 +679,7 @@ int dots_slab_set_buffers(dots_ctx *c, const dots_slab_buffers *b) {
 }
 
 int dots_slab_stage(dots_ctx *c, int stage, dots_step_stats *stats) {
-    int rc = check(c);
+    int rc = check(c, true);      // (the stages say themselves what they invalidate: carried sums live from stage 3 to the next stages 0 and 1)
     if (rc) return rc;
     if (c->shard_stride == 0) { set_error("slab_stage: context is not a time slab"); return DOTS_ERR_STATE; }
     if (!c->slab.b_send) { set_error("slab_stage: no exchange buffers (dots_slab_set_buffers)"); return DOTS_ERR_STATE; }
@@ -715,7 +715,7 @@ int dots_slab_stage(dots_ctx *c, int stage, dots_step_stats *stats) {
 }
 
 int dots_stream_wait(dots_ctx *c, void *other_stream, int ctx_waits) {
-    int rc = check(c, false, true);
+    int rc = check(c, true, true);      // (orders streams: changes neither state nor parameters)
     if (rc) return rc;
     hipStream_t other = (hipStream_t)other_stream;       // nullptr = the legacy default stream
     if (ctx_waits) {
@@ -1067,19 +1067,21 @@ int dots_front_setup(dots_ctx *c, const dots_front_desc *desc) {
     int rc = check(c);
     if (rc) return rc;
     if (c->lap_solver != DOTS_LAP_MODAL_PCG) { set_error("the direct solve needs the modal solver"); return DOTS_ERR_ARGUMENT; }
-    c->d.cn_sq = c->d.cn_g = nullptr;
+    c->d.cn_sq = c->d.cn_g = c->d.cn_lo = nullptr;
     if ((rc = front_setup(c, desc))) return rc;
     // DOTS_STEP_CARRY: the per-corner gathers steps 2+3 leave for the next right-hand side / projection (one GPU, pitch <= 128);
     // they belong to the direct solver's iteration and are released with the factor
-    if (c->shard_stride == 0 && c->d.TP <= 128 && c->carry_arrays) {
+    if (c->d.TP <= 128 && c->carry_arrays && c->d.nl > 0) {      // (one GPU or a time slab with nodes)
         const int64_t rows = (int64_t)3 * c->d.F;
-        const double *sq = nullptr, *g = nullptr;
-        if ((rc = front_upload<double>(c, &sq, nullptr, (2 * rows) << c->d.tp_shift)) || (rc = front_upload<double>(c, &g, nullptr, rows << c->d.tp_shift))) {
+        const double *sq = nullptr, *g = nullptr, *lo = nullptr;
+        if ((rc = front_upload<double>(c, &sq, nullptr, (2 * rows) << c->d.tp_shift)) || (rc = front_upload<double>(c, &g, nullptr, rows << c->d.tp_shift)) ||
+            (rc = front_upload<double>(c, &lo, nullptr, rows))) {
             front_release(c);
             return rc;
         }
         c->d.cn_sq = const_cast<double *>(sq);
         c->d.cn_g = const_cast<double *>(g);
+        c->d.cn_lo = const_cast<double *>(lo);
     }
     return 0;
 }

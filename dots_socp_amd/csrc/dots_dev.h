@@ -81,6 +81,7 @@ struct Dev {
     // NEXT iteration gather per corner, stored by steps 2+3 in corner-LIST order (row j = position in cidx; cpos: f*3+k -> j)
     double *cn_sq;           // [3F][2][TP] halves s = 0, 1 of sum_xyz (D (sz/sqrt3 B - beta_mid))^2, column = interval
     double *cn_g;            // [3F][TP]    sum_xyz area * hat * (B - E), column = node
+    double *cn_lo;           // [3F] time slab: the s = 1 half of interval t0 - 1 (formed at this slab's first node; summed into send_nsq)
     const int *cpos;         // [3F]
     // halos of a time slab (device arrays, written by dots_slab_unpack / the inverse transform; see SlabHalo in dots_api.hip)
     const double *X_lo;      // [V]  (A + lambda_c - mu) of interval t0 - 1           (right-hand side at node t0)
@@ -409,8 +410,10 @@ inline bool rhs_writes_modes(const Ctx *c) {
 
 inline bool soc_takes_inverse(const Ctx *c) { return rhs_writes_modes(c) && !time_modes_mfma_ok(c->d); }
 // steps 2+3 can form the next iteration's per-corner gathers (k_q_lambda_mult_carry: whole triangles per 192-lane workgroup)
+// (one GPU or a time slab; the direct solver's iteration)
 inline bool carry_possible(const Ctx *c) {
-    return c->d.cn_sq && c->ql_two && !c->d.slab && c->d.TP >= 4 && c->d.TP <= 128 && rhs_writes_modes(c);
+    return c->d.cn_sq && c->ql_two && c->d.TP >= 4 && c->d.TP <= 128 && c->use_front && c->front.n_nodes > 0 && c->lap_solver == DOTS_LAP_MODAL_PCG &&
+           (rhs_writes_modes(c) || c->d.slab);
 }
 // ... or the projection itself rides in the right-hand-side launch (enqueue-only iterations; TILE_ELEMS threads per tile)
 inline bool rhs_takes_soc(const Ctx *c) { return c->soc_with_rhs && rhs_writes_modes(c); }

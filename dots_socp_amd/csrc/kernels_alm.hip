@@ -81,6 +81,7 @@ __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double s
                 acc1 += q1[i];
             }
         }
+        if (!own1) acc1 = d.nsq_hi[v];      // (time slab: node t + 1 belongs to the next slab, which formed this half)
     } else {
         for (int j = j0; j < j1; ++j) {
             const int fk = d.cidx[j];
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(BLOCK) void k_soc_projection(Dev d, double sz, doub
 //            its entries are compared with B of THIS slab's first node and live in this slab's column 0 -- or B of the
 //            first node (KKT: Comp(rho, f(q)))
 // ------------------------------------------------------------------------------------------
+template <bool CARRIED>
 __global__ __launch_bounds__(BLOCK) void k_slab_pack_iteration(Dev d, double sz, double *__restrict__ send_x, double *__restrict__ send_nsq) {
     const int v = blockIdx.x * BLOCK + threadIdx.x;
     if (v >= d.V) return;
@@ -277,7 +279,15 @@ __global__ __launch_bounds__(BLOCK) void k_slab_pack_iteration(Dev d, double sz,
         const int iv = idxV(d, v, d.nl - 1);
         send_x[v] = d.A[iv] + d.lam[iv] - d.mu[iv];
     }
-    if (d.t0 > 0) send_nsq[v] = soc_half(d, v, -1, 1, sz * INV_SQRT3);
+    if (d.t0 > 0) {
+        if (CARRIED) {               // the corners' shares were left by steps 2+3 (cn_lo: same values, same order of the sum)
+            double acc = 0.0;
+            for (int j = d.cptr[v]; j < d.cptr[v + 1]; ++j) acc += d.cn_lo[j];
+            send_nsq[v] = acc;
+        } else {
+            send_nsq[v] = soc_half(d, v, -1, 1, sz * INV_SQRT3);
+        }
+    }
 }
 __global__ __launch_bounds__(BLOCK) void k_slab_pack_kkt(Dev d, double *__restrict__ send_mu, double *__restrict__ send_b) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -286,7 +296,8 @@ __global__ __launch_bounds__(BLOCK) void k_slab_pack_kkt(Dev d, double *__restri
 }
 int launch_slab_pack_iteration(Ctx *c) {
     if (c->d.nl == 0) return 0;
-    hipLaunchKernelGGL(k_slab_pack_iteration, dim3((c->d.V + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->d, c->prm.scale_z, c->slab.send_x, c->slab.send_nsq);
+    if (c->carry_valid) hipLaunchKernelGGL(k_slab_pack_iteration<true>, dim3((c->d.V + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->d, c->prm.scale_z, c->slab.send_x, c->slab.send_nsq);
+    else hipLaunchKernelGGL(k_slab_pack_iteration<false>, dim3((c->d.V + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->d, c->prm.scale_z, c->slab.send_x, c->slab.send_nsq);
     DOTS_HIP(hipGetLastError());
     return 0;
 }
@@ -363,6 +374,7 @@ __device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r
 }
 
 // Workgroups [n_rhs, gridDim.x) (when there are any): the cone projection, a quarter tile each, as in k_rhs_modes.
+template <bool CARRIED>
 __global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps, int n_rhs, double sz, double cd) {
     __shared__ double lds[4];
     if ((int)blockIdx.x >= n_rhs) {
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps, int 
         const int st = xcd_tile(b % G8, d.n_vtiles);
         if (st >= d.n_vtiles) return;
         const int e = (b / G8) * BLOCK + threadIdx.x, v = st * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (v < d.V && t < d.ni) soc_element<true>(d, v, t, sz, cd);
+        if (v < d.V && t < d.ni) soc_element<true, CARRIED>(d, v, t, sz, cd);
         return;
     }
     const int tile = xcd_tile(blockIdx.x, d.n_vtiles);
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs(Dev d, double r, double eps, int 
         for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
             const int v = v0 + (e >> d.tp_shift), t = e & (d.TP - 1);
             if (v >= d.V || t >= d.nl) continue;
-            const double b = rhs_value(d, v, t, r, eps);
+            const double b = rhs_value<CARRIED>(d, v, t, r, eps);
             d.cg_b[idxV(d, v, t)] = b;
             part[0] += b;
         }
@@ -668,8 +680,11 @@ int launch_rhs(Ctx *c, bool with_soc, double dv) {
     else if (rhs_writes_modes(c))
         hipLaunchKernelGGL(k_rhs_modes, dim3(with_soc ? 2 * g : g), dim3(RHS_NB), time_modes_tile_lds(c->d), c->stream, c->d, c->prm.r / c->prm.boundary_scale,
                            c->prm.eps, c->d.cg_p0, time_modes_chunk(c->d), g, c->prm.scale_z, c->prm.const_d);
+    else if (c->carry_valid)      // (a time slab of the direct solver's iteration)
+        hipLaunchKernelGGL(k_rhs<true>, dim3(with_soc ? g + g * (TILE_ELEMS / BLOCK) : g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale,
+                           c->prm.eps, g, c->prm.scale_z, c->prm.const_d);
     else
-        hipLaunchKernelGGL(k_rhs, dim3(with_soc ? g + g * (TILE_ELEMS / BLOCK) : g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale,
+        hipLaunchKernelGGL(k_rhs<false>, dim3(with_soc ? g + g * (TILE_ELEMS / BLOCK) : g), dim3(BLOCK), 0, c->stream, c->d, c->prm.r / c->prm.boundary_scale,
                            c->prm.eps, g, c->prm.scale_z, c->prm.const_d);
     DOTS_HIP(hipGetLastError());
     return 0;
@@ -1183,6 +1198,7 @@ __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carr
         st2(d.cn_sq + ((int64_t)(2 * j) << d.tp_shift) + t, D2{{q[0], q[1]}});
         st2(d.cn_sq + ((int64_t)(2 * j + 1) << d.tp_shift) + t, D2{{q[3], t + 2 < d.TP ? nxt : 0.0}});
         st2(d.cn_g + ((int64_t)j << d.tp_shift) + t, D2{{q[4], q[5]}});
+        if (t == 0 && has_prev_interval(d, 0)) d.cn_lo[j] = q[2];      // (time slab: the half of the previous slab's last interval formed here)
     }
     if (KKT) {
         __syncthreads();      // (the exchange values in xs have been read)
@@ -1538,7 +1554,7 @@ int launch_operator(Ctx *c, int op, double scale, const double *in, double *out)
 // the context is created, not inside the first iterations that happen to use them.
 void preload_alm_kernels() {
     const void *fns[] = {
-        (const void *)k_rhs, (const void *)k_rhs_modes, (const void *)k_rhs_modes2<false>, (const void *)k_rhs_modes2<true>,
+        (const void *)k_rhs<false>, (const void *)k_rhs<true>, (const void *)k_rhs_modes, (const void *)k_rhs_modes2<false>, (const void *)k_rhs_modes2<true>,
         (const void *)k_rhs_modes_mfma<false>, (const void *)k_rhs_modes_mfma<true>, (const void *)k_rhs_modes_mfma<false, true>, (const void *)k_rhs_modes2<false, true>,
         (const void *)k_soc_projection<true>, (const void *)k_soc_projection<false>, (const void *)k_soc_projection<true, true>,
         (const void *)k_q_lambda_mult_triangle<0>, (const void *)k_q_lambda_mult_triangle<1>, (const void *)k_q_lambda_mult_triangle<2>,

@@ -374,7 +374,7 @@ class ShardedAlmSolver(AlmSolver):
         sample = self.step_timers.begin(kind)
         async_ok = self._on_device and self.direct
         timed = sample and async_ok and len(self._timed_in_flight) <= 56
-        dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, timed=timed)
+        dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, timed=timed, carry=self._carry)
         wait = not async_ok
         self._kkt_halo_fresh = False
         if quiet:

@@ -90,7 +90,7 @@ class FakeDeviceProblem:
         s.bnd[0] = -p.boundary_scale * self.mu0 / (p.r * s.h)
         s.bnd[-1] = p.boundary_scale * self.mu1 / (p.r * s.h)
 
-    def step_flags(self, skip_z_mid=False, palm=False, timed=False):
+    def step_flags(self, skip_z_mid=False, palm=False, timed=False, carry=False):
         self.palm = palm
 
     def step_times(self, wait=False, capacity=64):
