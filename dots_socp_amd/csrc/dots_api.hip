@@ -293,7 +293,8 @@ static int build(Ctx *c, const dots_problem_desc *p) {
         t.VT = t.FT = TILE_ELEMS / tpg;
         t.n_vtiles = (d.V + t.VT - 1) / t.VT;
         t.n_ftiles = (3 * d.F + t.FT - 1) / t.FT;
-        c->slab_b_chunk = nnode + V;
+        c->slab_b_chunk = nnode;
+        c->slab_x_chunk = nnode + V;
     }
 
     // KKT normalisation constants (solver_socp.py:303-313): means of the broadcast weight arrays
@@ -361,12 +362,18 @@ static int slab_stage(Ctx *c, int stage) {
         case 0:       // [is_palm: step 0]; halos for the right-hand side and the projection
             if (d.nl > 0 && (rc = palm_step0(c))) return rc;
             return launch_slab_pack_iteration(c);
-        case 1:       // right-hand side of this slab's nodes + cone projection of its intervals -> b_send
+        case 1:       // right-hand side of this slab's nodes -> b_send, and the cone projection of its intervals (one launch)
+        case 6:       // ... the right-hand side alone: the caller starts the all-gather of b behind it and enqueues stage 5
+        case 5:       // ... the cone projection alone (it reads nothing the right-hand side or the solve writes); the multipliers of
+                      //     the slab's last interval go to the tail of x_send: the NEXT slab's steps 2+3 need them, after the solve
             if (d.nl > 0) {
-                if ((rc = launch_rhs(c, true))) return rc;
-                hipLaunchKernelGGL(k_slab_append_multiplier, dim3((d.V + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d,
-                                   c->slab.b_send + ((int64_t)d.V << d.tp_shift));
-                DOTS_HIP(hipGetLastError());
+                if (stage == 5) { if ((rc = launch_soc_projection(c, 1, false))) return rc; }
+                else if ((rc = launch_rhs(c, stage == 1))) return rc;
+                if (stage != 6) {
+                    hipLaunchKernelGGL(k_slab_append_multiplier, dim3((d.V + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d,
+                                       c->slab.x_send + ((int64_t)d.V << d.tp_shift));
+                    DOTS_HIP(hipGetLastError());
+                }
             }
             return 0;
         case 2:       // forward transform of this rank's modes + solve -> x_send
@@ -635,8 +642,8 @@ int64_t dots_slab_elems(dots_ctx *c, int which) {
     const int64_t nnode = (int64_t)c->d.V << c->d.tp_shift;
     switch (which) {
         case DOTS_SLAB_VERTEX_HALO: return c->d.V;
-        case DOTS_SLAB_B_CHUNK: return nnode + c->d.V;
-        case DOTS_SLAB_X_CHUNK: return nnode;
+        case DOTS_SLAB_B_CHUNK: return nnode;
+        case DOTS_SLAB_X_CHUNK: return nnode + c->d.V;
         case DOTS_SLAB_TRIANGLE_HALO: return (int64_t)3 * c->d.F;
         default: return -1;
     }
@@ -660,8 +667,9 @@ int dots_slab_set_buffers(dots_ctx *c, const dots_slab_buffers *b) {
     d.nsq_hi = b->recv_nsq;
     d.mu_lo = b->recv_mu;
     d.B_hi = b->recv_b;
-    // the previous slab appended its last interval's cone multipliers to its chunk of the right-hand-side all-gather
-    d.lamc_lo = (rank > 0 && d.nl > 0) ? b->b_recv + (int64_t)(rank - 1) * c->slab_b_chunk + ((int64_t)d.V << d.tp_shift) : b->recv_x;
+    // the previous slab appended its last interval's cone multipliers to its chunk of the SOLUTION all-gather (they are needed by
+    // steps 2+3, after it: the right-hand-side all-gather can then start before the projection has run)
+    d.lamc_lo = (rank > 0 && d.nl > 0) ? b->x_recv + (int64_t)(rank - 1) * c->slab_x_chunk + ((int64_t)d.V << d.tp_shift) : b->recv_x;
     const Dev g0 = c->dcg, t0 = c->dgt;
     c->dcg = d;                                 // the solver's view: same pitch, its own vectors, sigma slice, mode count
     c->dcg.cg_ncol = g0.cg_ncol; c->dcg.sigma = g0.sigma;
@@ -671,7 +679,7 @@ int dots_slab_set_buffers(dots_ctx *c, const dots_slab_buffers *b) {
     c->dgt.TP = t0.TP; c->dgt.tp_shift = t0.tp_shift; c->dgt.t0 = 0; c->dgt.nl = d.T + 1; c->dgt.ni = d.T; c->dgt.slab = 0;
     c->dgt.VT = t0.VT; c->dgt.FT = t0.FT; c->dgt.n_vtiles = t0.n_vtiles; c->dgt.n_ftiles = t0.n_ftiles;
     // the PCG's warm start (its own previous solution) and the buffers' padding start from zero
-    DOTS_HIP(hipMemsetAsync(b->x_send, 0, sizeof(double) * ((size_t)d.V << d.tp_shift), c->stream));
+    DOTS_HIP(hipMemsetAsync(b->x_send, 0, sizeof(double) * (size_t)c->slab_x_chunk, c->stream));
     DOTS_HIP(hipMemsetAsync(b->b_send, 0, sizeof(double) * (size_t)c->slab_b_chunk, c->stream));
     DOTS_HIP(hipStreamSynchronize(c->stream));
     c->slab_stage = 0;
@@ -683,11 +691,13 @@ int dots_slab_stage(dots_ctx *c, int stage, dots_step_stats *stats) {
     if (rc) return rc;
     if (c->shard_stride == 0) { set_error("slab_stage: context is not a time slab"); return DOTS_ERR_STATE; }
     if (!c->slab.b_send) { set_error("slab_stage: no exchange buffers (dots_slab_set_buffers)"); return DOTS_ERR_STATE; }
-    if (stage < 0 || stage > 4) { set_error("slab_stage: unknown stage"); return DOTS_ERR_ARGUMENT; }
-    if (stage <= 3 && stage != c->slab_stage) { set_error("slab_stage: stages must be called in the order 0, 1, 2, 3"); return DOTS_ERR_STATE; }
+    if (stage < 0 || stage > 6) { set_error("slab_stage: unknown stage"); return DOTS_ERR_ARGUMENT; }
+    // order: 0, 1, 2, 3 -- or with stage 1 in two halves: 0, 6, 5, 2, 3 (slab_stage = the next stage expected; 5: the projection is due)
+    const bool in_order = stage == 4 || stage == c->slab_stage || (stage == 6 && c->slab_stage == 1);
+    if (!in_order) { set_error("slab_stage: stages must be called in the order 0, 1, 2, 3 (or 0, 6, 5, 2, 3)"); return DOTS_ERR_STATE; }
     if (stage == 4 && c->slab_stage != 0) { set_error("slab_stage: the KKT halos are packed between iterations"); return DOTS_ERR_STATE; }
     if (!stats) {
-        hipEvent_t *tv = stage <= 3 ? time_slot(c, 1 + stage) : nullptr;
+        hipEvent_t *tv = stage != 4 ? time_slot(c, 1 + stage) : nullptr;
         rc = tv ? (int)hipEventRecord(tv[0], c->stream) : 0;
         if (!rc) rc = slab_stage(c, stage);
         if (!rc && tv && hipEventRecord(tv[1], c->stream) != hipSuccess) rc = DOTS_ERR_HIP;
@@ -705,12 +715,15 @@ int dots_slab_stage(dots_ctx *c, int stage, dots_step_stats *stats) {
         DOTS_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
         memset(stats, 0, sizeof *stats);
         stats->ms_total = t;
-        if (stage == 0) stats->ms_rhs = t;                             // packing the halos (as dots_step_times books it)
+        if (stage == 0 || stage == 6) stats->ms_rhs = t;              // packing the halos (as dots_step_times books it); the right-hand side alone
+        if (stage == 5) stats->ms_soc = t;
         if (stage == 1) stats->ms_rhs = stats->ms_soc = 0.5 * t;      // one launch: right-hand side and projection together
         if (stage == 2) { stats->ms_laplacian = t; stats->cg_iterations = stats->cg_last_iterations = c->last_cg_iters; }
         if (stage == 3) { stats->ms_q_lambda_multiplier = t; stats->alm_iterations = 1; }
     }
     if (stage <= 3) c->slab_stage = (stage + 1) & 3;
+    else if (stage == 6) c->slab_stage = 5;
+    else if (stage == 5) c->slab_stage = 2;
     return 0;
 }
 
@@ -799,7 +812,8 @@ int dots_step_times(dots_ctx *c, dots_step_stats *out, int capacity, int wait, i
             const int stage = kind - 1;
             DOTS_HIP(hipEventElapsedTime(&t, tv[0], tv[1]));
             st.ms_total = t;
-            if (stage == 0) st.ms_rhs = t;                              // packing the halos
+            if (stage == 0 || stage == 6) st.ms_rhs = t;                // packing the halos; the right-hand side alone
+            if (stage == 5) st.ms_soc = t;
             if (stage == 1) st.ms_rhs = st.ms_soc = 0.5 * t;            // one launch: right-hand side and projection together
             if (stage == 2) st.ms_laplacian = t;
             if (stage == 3) { st.ms_q_lambda_multiplier = t; st.alm_iterations = 1; }

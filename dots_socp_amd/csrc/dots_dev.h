@@ -282,7 +282,8 @@ struct Ctx {
     int shard_ranks = 0;    // ranks with at least one node
     Dev dgt{};              // global-time view for the transforms of a slab context: pitch >= T + 1, Q
     dots_slab_buffers slab{};     // exchange buffers (caller's device memory, dots_slab_set_buffers)
-    int64_t slab_b_chunk = 0;     // doubles one rank contributes to the right-hand-side all-gather: V * pitch + V
+    int64_t slab_b_chunk = 0;     // doubles one rank contributes to the right-hand-side all-gather: V * pitch
+    int64_t slab_x_chunk = 0;     // ... to the all-gather of the mode-space solution: V * pitch + V (the last interval's cone multipliers)
     int slab_stage = 0;           // next stage dots_slab_stage expects
     int kkt_halo_fresh = 0;       // mu_lo / B_hi belong to the current iterate
     dots_params prm{};

@@ -797,7 +797,7 @@ int cg_finish_sharded(Ctx *c) {
     const Dev &d = c->d, &dt = c->dgt;
     if (d.nl == 0) return 0;
     if (!time_modes_tile_ok(dt)) { set_error("time slabs need T + 1 <= 256"); return DOTS_ERR_STATE; }
-    const Gathered xg{c->slab.x_recv, (int64_t)d.V << c->dcg.tp_shift, c->dcg.tp_shift, c->shard_stride};
+    const Gathered xg{c->slab.x_recv, c->slab_x_chunk, c->dcg.tp_shift, c->shard_stride};
     hipLaunchKernelGGL(k_time_modes_inv_gathered_tile, dim3(xcd_grid(dt.n_vtiles)), dim3(BLOCK), time_modes_tile_lds(dt), c->stream, dt, xg, d.phi,
                        d.tp_shift, d.t0, d.nl, d.phi_hi, time_modes_chunk(dt));
     DOTS_HIP(hipGetLastError());

@@ -9,14 +9,15 @@ Every operator of an ALM iteration is local in the time index except nearest-nei
     the corner entries compared with its nodes' B  (device bytes: state / R),
   * factorises and solves the time modes ``[r s, (r+1) s)``  (factor bytes / R, no communication inside the solve).
 
-One iteration (``dots_slab_stage`` 0-3, include/dots_socp_hip.h) has three exchanges:
+One iteration (``dots_slab_stage`` 0, 6, 5, 2, 3; include/dots_socp_hip.h) has three exchanges:
 
     stage 0    pack two V-sized halos                      -> neighbour exchange (xGMI point-to-point):
                (A + lambda_c - mu) of the last interval forward, the half of the cone norms that pairs with the first
                node's B backward
-    stage 1    right-hand side + cone projection           -> all-gather of the right-hand side  (8 (T+1) V bytes in total;
-               each rank appends its last interval's cone multipliers for the next slab)
-    stage 2    forward transform of own modes + sweeps     -> all-gather of the mode-space solution  (8 (T+1) V bytes)
+    stage 6    right-hand side                             -> all-gather of the right-hand side  (8 (T+1) V bytes in total)
+    stage 5    cone projection, on the context's stream WHILE that all-gather runs (it reads nothing the exchange writes)
+    stage 2    forward transform of own modes + sweeps     -> all-gather of the mode-space solution  (8 (T+1) V bytes; each
+               rank appends its last interval's cone multipliers for the next slab's steps 2+3)
     stage 3    inverse transform for own nodes (+ the next slab's first node, computed redundantly: phi needs no halo),
                steps 2 and 3
 
@@ -373,7 +374,7 @@ class ShardedAlmSolver(AlmSolver):
         kind = "quiet" if quiet else "read-back"
         sample = self.step_timers.begin(kind)
         async_ok = self._on_device and self.direct
-        timed = sample and async_ok and len(self._timed_in_flight) <= 56
+        timed = sample and async_ok and len(self._timed_in_flight) <= 55
         dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, timed=timed, carry=self._carry)
         wait = not async_ok
         self._kkt_halo_fresh = False
@@ -383,7 +384,9 @@ class ShardedAlmSolver(AlmSolver):
             self.untimed_steps += 1
         events = []
 
-        def exchange(fn):
+        def exchange(fn, between=None):
+            """``between``: device work enqueued on the context's stream AFTER the exchange has been handed to the communication
+            stream and BEFORE the context waits for it: the two overlap."""
             t0 = time.perf_counter()
             self._order(ctx_waits=False)
             if timed:
@@ -393,19 +396,25 @@ class ShardedAlmSolver(AlmSolver):
             if timed:
                 e1.record(torch.cuda.current_stream(self._tdev))
                 events.append((e0, e1))
+            dt = time.perf_counter() - t0
+            if between is not None:
+                between()
+            t1 = time.perf_counter()
             self._order(ctx_waits=True)
-            return time.perf_counter() - t0
+            return dt + time.perf_counter() - t1
 
         t_comm = 0.0
         stats = [dev.slab_stage(0, wait=wait)]
         t_comm += exchange(lambda: comm.exchange(self.n_active, fwd=(buf["send_x"], buf["recv_x"]), bwd=(buf["send_nsq"], buf["recv_nsq"]), sync=wait))
-        stats.append(dev.slab_stage(1, wait=wait))
-        t_comm += exchange(lambda: comm.all_gather(buf["b_recv"], buf["b_send"], sync=wait))
+        # stage 1 in two halves: the all-gather of the right-hand side starts as soon as it is packed (stage 6) and the cone
+        # projection (stage 5: it reads nothing the exchange or the solve writes) runs behind it on the context's stream
+        stats.append(dev.slab_stage(6, wait=wait))
+        t_comm += exchange(lambda: comm.all_gather(buf["b_recv"], buf["b_send"], sync=wait), between=lambda: stats.append(dev.slab_stage(5, wait=wait)))
         stats.append(dev.slab_stage(2, wait=wait))
         t_comm += exchange(lambda: comm.all_gather(buf["x_recv"], buf["x_send"], sync=wait))
         stats.append(dev.slab_stage(3, wait=wait))
         if timed:
-            self._timed_in_flight.extend([kind] * 4)
+            self._timed_in_flight.extend([kind] * 5)
             self._comm_events.append((kind, events))
         if wait:        # host-staged exchanges or the PCG: every stage was waited for and timed, the exchanges by the host's clock
             for st in stats:

@@ -227,17 +227,22 @@ int dots_step_times(dots_ctx *ctx, dots_step_stats *out, int capacity, int wait,
  *               send_nsq [V]  the s = 1 half of the cone norms of the interval that ends at this slab's first node
  *                             (formed from this slab's B and beta_mid)                    -> previous rank's recv_nsq
  *   (caller)  neighbour exchange (two V-sized messages per slab boundary)
- *   stage 1   right-hand side of this slab's nodes + cone projection of its intervals; b_send = [V][pitch] right-hand
- *             side followed by [V] cone multipliers of the slab's last interval
- *   (caller)  all-gather of b_send into b_recv = [n_ranks][V * pitch + V]
- *   stage 2   forward time transform restricted to this rank's modes, solve (sweeps or PCG); x_send = [V][pitch] solution
- *   (caller)  all-gather of x_send into x_recv = [n_ranks][V * pitch]
+ *   stage 1   right-hand side of this slab's nodes -> b_send = [V][pitch], and the cone projection of its intervals (one launch);
+ *             the cone multipliers of the slab's last interval go to the tail [V] of x_send (the next slab's steps 2+3 read them)
+ *             -- or in two halves, so that the exchange overlaps the projection:
+ *   stage 6     the right-hand side alone;  (caller) starts the all-gather of b_send;
+ *   stage 5     the cone projection alone, enqueued behind stage 6 on the context's stream while the all-gather runs on the
+ *               caller's (the projection reads nothing the right-hand side, the all-gather or the solve writes: steps 1-1 and
+ *               1-2 of solver_socp.py:674-696 minimise a separable block -- the reference runs them on two threads)
+ *   (caller)  all-gather of b_send into b_recv = [n_ranks][V * pitch]
+ *   stage 2   forward time transform restricted to this rank's modes, solve (sweeps or PCG); x_send = [V][pitch] solution (+ tail)
+ *   (caller)  all-gather of x_send into x_recv = [n_ranks][V * pitch + V]
  *   stage 3   inverse time transform for this slab's nodes (+ the next slab's first node, computed redundantly),
  *             steps 2 and 3
  *   stage 4   (only before KKT residuals are evaluated) pack send_mu [V] (mu of the last interval -> next rank) and
  *             send_b [3F] (B of the first node -> previous rank); the caller exchanges them, then dots_kkt_sums
  *
- * Stages must be called in order 0,1,2,3 (DOTS_ERR_STATE otherwise).  With stats == NULL a stage is only enqueued on the
+ * Stages must be called in order 0,1,2,3 or 0,6,5,2,3 (DOTS_ERR_STATE otherwise).  With stats == NULL a stage is only enqueued on the
  * context's stream: the caller orders its exchanges against it with dots_stream_wait (no host wait anywhere).
  * All buffers are DEVICE memory owned by the caller (e.g. torch tensors handed to RCCL), registered once with
  * dots_slab_set_buffers; sizes from dots_slab_elems.  Results are bit-identical for every number of ranks, 1 included
@@ -246,8 +251,8 @@ int dots_step_times(dots_ctx *ctx, dots_step_stats *out, int capacity, int wait,
 typedef struct dots_slab_buffers {
     double *send_x, *send_nsq;      /* [V] each: stage 0 output                                              */
     double *recv_x, *recv_nsq;      /* [V] each: from the previous / next rank                               */
-    double *b_send, *b_recv;        /* [V * pitch + V], [n_ranks][V * pitch + V]                             */
-    double *x_send, *x_recv;        /* [V * pitch],     [n_ranks][V * pitch]                                 */
+    double *b_send, *b_recv;        /* [V * pitch],     [n_ranks][V * pitch]                                 */
+    double *x_send, *x_recv;        /* [V * pitch + V], [n_ranks][V * pitch + V]                             */
     double *send_mu, *send_b;       /* [V], [3F]: stage 4 output                                             */
     double *recv_mu, *recv_b;       /* [V], [3F]: from the previous / next rank                              */
 } dots_slab_buffers;

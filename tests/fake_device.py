@@ -129,7 +129,7 @@ class FakeDeviceProblem:
 
     # ---- exchange buffers
     def slab_elems(self, which):
-        return {"vertex_halo": self.V, "b_chunk": self.V * self.pitch + self.V, "x_chunk": self.V * self.pitch, "triangle_halo": 3 * self.F}[which]
+        return {"vertex_halo": self.V, "b_chunk": self.V * self.pitch, "x_chunk": self.V * self.pitch + self.V, "triangle_halo": 3 * self.F}[which]
 
     def slab_set_buffers(self, **pointers):
         n = self.n_ranks
@@ -170,7 +170,7 @@ class FakeDeviceProblem:
     def slab_stage(self, stage, wait=False):
         s, b = self.s, self.buf
         n0, nl, ni, T = self.node0, self.nl, self.ni, self.T
-        assert stage == 4 or stage == self.stage, "stages out of order"
+        assert stage == 4 or stage == self.stage or (stage == 6 and self.stage == 1), "stages out of order"
         has_next, has_prev = n0 + nl <= T and nl > 0, n0 > 0 and nl > 0
         if stage == 0:
             if getattr(self, "palm", False):
@@ -179,12 +179,17 @@ class FakeDeviceProblem:
                 b["send_x"][:] = self._X()[n0 + nl - 1]
             if has_prev:
                 b["send_nsq"][:] = self._half_norms(n0 - 1)
-        elif stage == 1:
+        elif stage in (1, 6):      # right-hand side (1: and the projection, in one stage)
             if has_prev:
                 self._check("recv_x", b["recv_x"], self._X()[n0 - 1])
+            self.rhs = s.laplacian_rhs()
+            out = b["b_send"]
+            out[:] = 0.0
+            if nl:
+                out.reshape(self.V, self.pitch)[:, :nl] = self.rhs[n0:n0 + nl].T
+        if stage in (1, 5):        # cone projection; the multipliers of the slab's last interval ride in the solution's all-gather
             if has_next:
                 self._check("recv_nsq", b["recv_nsq"], self._half_norms(n0 + nl - 1))
-            self.rhs = s.laplacian_rhs()
             self.B_old, self.bm_old = s.B.copy(), s.beta_mid.copy()
             s.step_soc_projection()
             w_fst = s.d - s.sz * s.A - s.beta_fst          # the cone multiplier, as the projection forms it
@@ -192,22 +197,15 @@ class FakeDeviceProblem:
             nrm = np.sqrt(s.c2v_one_T.dot((w_mid ** 2).sum(axis=(1, 4)).reshape(-1)).reshape(T, s.V) + (s.d + s.sz * s.A - s.beta_end) ** 2)
             with np.errstate(divide="ignore", invalid="ignore"):
                 self.lam = np.clip(0.5 * (1.0 + w_fst / nrm), 0.0, 1.0)
-            out = b["b_send"]
-            out[:] = 0.0
-            if nl:
-                out[:self.V * self.pitch].reshape(self.V, self.pitch)[:, :nl] = self.rhs[n0:n0 + nl].T
-                if has_next:
-                    out[self.V * self.pitch:] = self.lam[n0 + nl - 1]
+            b["x_send"][self.V * self.pitch:] = self.lam[n0 + nl - 1] if (nl and has_next) else 0.0
         elif stage == 2:
             chunks = b["b_recv"].reshape(self.n_ranks, -1)
             rhs = np.zeros_like(self.rhs)
             for t in range(T + 1):
                 p, j = divmod(t, self.stride)
-                rhs[t] = chunks[p, :self.V * self.pitch].reshape(self.V, self.pitch)[:, j]
+                rhs[t] = chunks[p].reshape(self.V, self.pitch)[:, j]
             self._check("b", rhs, self.rhs)
-            if has_prev:
-                self._check("lamc_lo", chunks[self.rank - 1, self.V * self.pitch:], self.lam[n0 - 1])
-            out = b["x_send"].reshape(self.V, self.pitch)
+            out = b["x_send"][:self.V * self.pitch].reshape(self.V, self.pitch)
             out[:] = 0.0
             for j, a in enumerate(range(n0, n0 + nl)):
                 hat = self.Q[:, a] @ rhs
@@ -215,7 +213,10 @@ class FakeDeviceProblem:
                     hat = hat - hat.mean()
                 out[:, j] = self._solve_mode(a, hat)
         elif stage == 3:
-            g = b["x_recv"].reshape(self.n_ranks, self.V, self.pitch)
+            chunks = b["x_recv"].reshape(self.n_ranks, -1)
+            if has_prev:
+                self._check("lamc_lo", chunks[self.rank - 1, self.V * self.pitch:], self.lam[n0 - 1])
+            g = chunks[:, :self.V * self.pitch].reshape(self.n_ranks, self.V, self.pitch)
             xhat = np.zeros((T + 1, self.V))
             for a in range(T + 1):
                 xhat[a] = g[a // self.stride, :, a % self.stride]
@@ -235,6 +236,10 @@ class FakeDeviceProblem:
             self.kkt_halo_fresh = True
         if stage <= 3:
             self.stage = (stage + 1) & 3
+        elif stage == 6:
+            self.stage = 5
+        elif stage == 5:
+            self.stage = 2
         return _stats(alm_iterations=1 if stage == 3 else 0) if wait else None
 
     # ---- scalars: every rank contributes (slot 0 counts the contributions), the residuals come from the whole state

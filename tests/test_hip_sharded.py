@@ -97,11 +97,22 @@ class SlabGroup:
             b[recv].copy_(allv)
         self.torch.cuda.synchronize()
 
-    def iterate(self):
+    def iterate(self, split=None):
+        """``split``: stage 1 in its two halves (6: right-hand side, 5: projection) around the all-gather of b; default: every other iteration."""
+        self.n_iterations = getattr(self, "n_iterations", 0) + 1
+        if split is None:
+            split = self.n_iterations % 2 == 0
         self.each(lambda d: d.slab_stage(0))
         self.neighbours(("send_x", "recv_x"), ("send_nsq", "recv_nsq"))
-        self.each(lambda d: d.slab_stage(1))
-        self.gather("b_send", "b_recv")
+        if split:
+            self.each(lambda d: d.slab_stage(6))
+            self.gather("b_send", "b_recv")
+            self.each(lambda d: d.slab_stage(5))
+            with pytest.raises(Exception, match="order"):
+                self.devs[0].slab_stage(5)
+        else:
+            self.each(lambda d: d.slab_stage(1))
+            self.gather("b_send", "b_recv")
         self.each(lambda d: d.slab_stage(2))
         self.gather("x_send", "x_recv")
         self.each(lambda d: d.slab_stage(3))
@@ -184,6 +195,8 @@ def test_slab_stage_order_and_stale_halos_are_errors():
     d = group.devs[0]
     with pytest.raises(_lib.HipLibraryError, match="order"):
         d.slab_stage(2)
+    with pytest.raises(_lib.HipLibraryError, match="order"):
+        d.slab_stage(5)               # the projection alone comes after the right-hand side alone (stage 6)
     with pytest.raises(_lib.HipLibraryError, match="slab"):
         d.step(1)
     with pytest.raises(_lib.HipLibraryError, match="slab"):
