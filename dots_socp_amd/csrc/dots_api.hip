@@ -245,6 +245,7 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     const int64_t nnode = (int64_t)V << sh;
     if (!sharded && (rc = dev_alloc(c, &d.cg_b, nnode))) return rc;      // a slab writes its right-hand side into slab.b_send
     if ((rc = dev_alloc(c, &d.lamc, nnode))) return rc;
+    if (!sharded && ((rc = dev_alloc(c, &c->zf_alt, nnode)) || (rc = dev_alloc(c, &c->ze_alt, nnode)) || (rc = dev_alloc(c, &c->lamc_alt, nnode)))) return rc;
     if (sharded) {
         double *hv = nullptr;
         if ((rc = dev_alloc(c, &hv, V))) return rc;
@@ -264,7 +265,7 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     if (!sharded && tp >= 4) {      // DOTS_STEP_KKT_SUMS: per-workgroup partial sums of the steps-2+3 launch (carry or tile mapping)
         const int64_t tw = tp <= 128 ? (2 * 192 / tp) / 3 : 1;
         c->kkt_fused_cap_v = gv;
-        c->kkt_fused_cap_f = std::max<int64_t>(xcd_grid((int)((F + tw - 1) / tw)), (int64_t)gf * (TILE_ELEMS / (2 * BLOCK)));
+        c->kkt_fused_cap_f = xcd_grid((int)((F + tw - 1) / tw));
         if ((rc = dev_alloc(c, &c->kkt_fused.part_v, (int64_t)N_VSUMS * c->kkt_fused_cap_v))) return rc;
         if ((rc = dev_alloc(c, &c->kkt_fused.part_f, (int64_t)N_FSUMS * c->kkt_fused_cap_f))) return rc;
     }
@@ -421,8 +422,17 @@ static int run_iteration_body(Ctx *c, dots_step_stats *st, hipEvent_t *tv) {
     if ((rc = palm_step0(c))) return rc;
     // the right-hand side of this iteration was enqueued behind the KKT kernels of the last one (DOTS_STEP_RHS_AHEAD) and nothing
     // it reads has changed since: start at the solve; the projection then runs with the inverse transform
-    const bool ahead = c->rhs_ahead && !c->step_palm;
+    const int ahead_kind = c->step_palm ? 0 : c->rhs_ahead;
+    const bool ahead = ahead_kind != 0;
     c->rhs_ahead = 0;
+    if (ahead_kind == 2) {      // the projection ran ahead too: its results become the current z_fst, z_end and cone multiplier
+        std::swap(c->d.zf, c->zf_alt);
+        std::swap(c->d.ze, c->ze_alt);
+        std::swap(c->d.lamc, c->lamc_alt);
+        c->dcg.zf = c->dgt.zf = c->d.zf;
+        c->dcg.ze = c->dgt.ze = c->d.ze;
+        c->dcg.lamc = c->dgt.lamc = c->d.lamc;
+    }
     if (!st) {   // asynchronous: enqueue only (the direct solver needs no host round trip); nothing is timed
         c->zmid_stale = c->step_skip_zmid;
         if (rhs_takes_soc(c) && !ahead) {   // [right-hand side + projection] -> sweeps -> inverse transform -> steps 2+3
@@ -437,12 +447,12 @@ static int run_iteration_body(Ctx *c, dots_step_stats *st, hipEvent_t *tv) {
             if (tv) c->tkind[(c->t_head + c->t_count - 1) % Ctx::TIME_SLOTS] = TKIND_FUSED;
             return 0;
         }
-        const bool fuse = soc_takes_inverse(c);
+        const bool fuse = soc_takes_inverse(c) && ahead_kind != 2;
         if (!ahead && (rc = launch_rhs(c))) return rc;
         MARK(1);
         if ((rc = cg_solve(c, nullptr, fuse))) return rc;
         MARK(2);
-        if ((rc = launch_soc_projection(c, 1, fuse))) return rc;
+        if (ahead_kind != 2 && (rc = launch_soc_projection(c, 1, fuse))) return rc;
         MARK(3);
         if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
         MARK(4);
@@ -453,10 +463,10 @@ static int run_iteration_body(Ctx *c, dots_step_stats *st, hipEvent_t *tv) {
     DOTS_HIP(hipEventRecord(c->ev[0], c->stream));
     if (!ahead && (rc = launch_rhs(c))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[1], c->stream));
-    const bool fuse = soc_takes_inverse(c);
+    const bool fuse = soc_takes_inverse(c) && ahead_kind != 2;
     if ((rc = cg_solve(c, st, fuse))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[2], c->stream));
-    if ((rc = launch_soc_projection(c, 1, fuse))) return rc;
+    if (ahead_kind != 2 && (rc = launch_soc_projection(c, 1, fuse))) return rc;
     DOTS_HIP(hipEventRecord(c->ev[3], c->stream));
     if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
     c->zmid_stale = c->step_skip_zmid;
@@ -1081,21 +1091,22 @@ int dots_front_setup(dots_ctx *c, const dots_front_desc *desc) {
     int rc = check(c);
     if (rc) return rc;
     if (c->lap_solver != DOTS_LAP_MODAL_PCG) { set_error("the direct solve needs the modal solver"); return DOTS_ERR_ARGUMENT; }
-    c->d.cn_sq = c->d.cn_g = c->d.cn_lo = nullptr;
+    c->d.cn_sq = c->d.cn_g = c->d.cn_lo = c->d.cn_e = nullptr;
     if ((rc = front_setup(c, desc))) return rc;
     // DOTS_STEP_CARRY: the per-corner gathers steps 2+3 leave for the next right-hand side / projection (one GPU, pitch <= 128);
     // they belong to the direct solver's iteration and are released with the factor
     if (c->d.TP <= 128 && c->carry_arrays && c->d.nl > 0) {      // (one GPU or a time slab with nodes)
         const int64_t rows = (int64_t)3 * c->d.F;
-        const double *sq = nullptr, *g = nullptr, *lo = nullptr;
+        const double *sq = nullptr, *g = nullptr, *lo = nullptr, *e = nullptr;
         if ((rc = front_upload<double>(c, &sq, nullptr, (2 * rows) << c->d.tp_shift)) || (rc = front_upload<double>(c, &g, nullptr, rows << c->d.tp_shift)) ||
-            (rc = front_upload<double>(c, &lo, nullptr, rows))) {
+            (rc = front_upload<double>(c, &lo, nullptr, rows)) || (c->shard_stride == 0 && (rc = front_upload<double>(c, &e, nullptr, rows << c->d.tp_shift)))) {
             front_release(c);
             return rc;
         }
         c->d.cn_sq = const_cast<double *>(sq);
         c->d.cn_g = const_cast<double *>(g);
         c->d.cn_lo = const_cast<double *>(lo);
+        c->d.cn_e = const_cast<double *>(e);
     }
     return 0;
 }

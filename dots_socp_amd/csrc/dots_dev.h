@@ -81,6 +81,7 @@ struct Dev {
     // NEXT iteration gather per corner, stored by steps 2+3 in corner-LIST order (row j = position in cidx; cpos: f*3+k -> j)
     double *cn_sq;           // [3F][2][TP] halves s = 0, 1 of sum_xyz (D (sz/sqrt3 B - beta_mid))^2, column = interval
     double *cn_g;            // [3F][TP]    sum_xyz area * hat * (B - E), column = node
+    double *cn_e;            // [3F][TP]    sum_xyz area * hat * E, column = node: the gather of Dual(alpha) (read-back iterations only)
     double *cn_lo;           // [3F] time slab: the s = 1 half of interval t0 - 1 (formed at this slab's first node; summed into send_nsq)
     const int *cpos;         // [3F]
     // halos of a time slab (device arrays, written by dots_slab_unpack / the inverse transform; see SlabHalo in dots_api.hip)
@@ -351,7 +352,9 @@ struct Ctx {
     int front_planes[65]{};       // update planes the forward launch of a band reads per node (0, 2, 4 or 8)
     int front_vec2 = 1;           // two modes per lane in the sweeps (DOTS_FRONT_VEC2: 0 never, 1 / 2 wherever the pitch allows, 3 only where bandwidth-bound)
     int rhs_ahead_armed = 0;      // DOTS_STEP_RHS_AHEAD: the next KKT launch is followed by the next iteration's right-hand side
-    int rhs_ahead = 0;            // ... which is on the stream and still valid (any call that changes state or parameters clears it)
+    int rhs_ahead = 0;            // ... which is on the stream and still valid (any call that changes state or parameters clears it); 2: with the
+                                  // cone projection, whose results (z_fst, z_end, the cone multiplier) wait in the alternate buffers below
+    double *zf_alt = nullptr, *ze_alt = nullptr, *lamc_alt = nullptr;   // [V][TP] each (one GPU): written ahead, swapped in by the step that takes them
     int front_rb_max = 4;         // most rows (columns) of a node per workgroup (DOTS_FRONT_RB: 1, 2 or 4, for A/B measurements)
     double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps, merged blocks as stored)
     double front_bytes_unmerged = 0.0;   // the same for one launch per tree height (no merged bands)

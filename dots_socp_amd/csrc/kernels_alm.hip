@@ -965,6 +965,10 @@ __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, doub
         if (CARRY) {      // the expressions of soc_element2 / rhs_value2 on the values those will find in memory
             const bool node = tu < d.nl;
             const double de = bn - En.v[u];
+            if (KKT) {    // ... and of Dual(alpha)'s gather (kkt_vertex_body2: sum over the corners of area * hat . E)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) xl[(CARRY_VALUES + k * 2 + u) * CARRY_NB] = node ? (hk[k] * area) * En.v[u] : 0.0;
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 xl[(k * 6 + u) * CARRY_NB] = has0 ? soc_w2(Dk[k], sBn, n0[k].v[u]) : 0.0;               // s = 0 half of interval tu
@@ -1157,8 +1161,10 @@ __device__ __forceinline__ void store_fused(const double (&v)[N], const int (&sl
 }
 template <int ZMODE, bool KKT = false, bool DIV = false>
 __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carry(Dev d, double sz, double tau, int n_fwg, int tri_per_wg, double cd, double cr,
-                                                                                  KktArgs ka, KktFused kf, double dv) {
-    __shared__ double xs[CARRY_VALUES * CARRY_NB];
+                                                                                  KktArgs ka, KktFused kf, double dv, int emit) {
+    // emit: bit 0 the gathers of the next right-hand side / projection (cn_sq, cn_g: DOTS_STEP_CARRY), bit 1 those of this
+    // iterate's Dual(alpha) residual (cn_e: DOTS_STEP_KKT_SUMS, KKT instantiations only)
+    __shared__ double xs[(CARRY_VALUES + (KKT ? 6 : 0)) * CARRY_NB];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= n_fwg) {
         const int vb = blockIdx.x - n_fwg, vt = xcd_tile(vb, d.n_vtiles);
@@ -1195,44 +1201,22 @@ __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carr
 #ifdef DOTS_CARRY_CPOS_LATE
         const int j = d.cpos[f * 3 + c];
 #endif
-        st2(d.cn_sq + ((int64_t)(2 * j) << d.tp_shift) + t, D2{{q[0], q[1]}});
-        st2(d.cn_sq + ((int64_t)(2 * j + 1) << d.tp_shift) + t, D2{{q[3], t + 2 < d.TP ? nxt : 0.0}});
-        st2(d.cn_g + ((int64_t)j << d.tp_shift) + t, D2{{q[4], q[5]}});
-        if (t == 0 && has_prev_interval(d, 0)) d.cn_lo[j] = q[2];      // (time slab: the half of the previous slab's last interval formed here)
+        if (emit & 1) {
+            st2(d.cn_sq + ((int64_t)(2 * j) << d.tp_shift) + t, D2{{q[0], q[1]}});
+            st2(d.cn_sq + ((int64_t)(2 * j + 1) << d.tp_shift) + t, D2{{q[3], t + 2 < d.TP ? nxt : 0.0}});
+            st2(d.cn_g + ((int64_t)j << d.tp_shift) + t, D2{{q[4], q[5]}});
+            if (t == 0 && has_prev_interval(d, 0)) d.cn_lo[j] = q[2];      // (time slab: the half of the previous slab's last interval formed here)
+        }
+        if (KKT && (emit & 2)) {
+            const double *x0 = xs + (CARRY_VALUES + c * 2) * CARRY_NB + t0, *x1 = x0 + CARRY_NB;
+            st2(d.cn_e + ((int64_t)j << d.tp_shift) + t, D2{{sum3(x0[0], x0[L], x0[2 * L]), sum3(x1[0], x1[L], x1[2 * L])}});
+        }
     }
     if (KKT) {
         __syncthreads();      // (the exchange values in xs have been read)
         block_sum<KF_N, CARRY_NB / 64>(kt, xs);
         if (tid == 0) store_fused<KF_N>(kt, KF_SLOT, N_VSUMS, kf.part_f, kf.nf, blockIdx.x);
     }
-}
-
-// Steps 2+3 of an iteration whose residuals are read back but whose successor does NOT start from the state it leaves (a penalty
-// update follows: no carry): the tile mapping of k_q_lambda_mult_triangle2, the lane of ql2_lane, the fused KKT sums.
-template <int ZMODE>
-__global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle2_kkt(Dev d, double sz, double tau, int nf8, double cd, double cr, KktArgs ka, KktFused kf) {
-    __shared__ double lds[(KV_N > KF_N ? KV_N : KF_N) * 4];
-    constexpr int SUB = TILE_ELEMS / (2 * BLOCK);
-    if ((int)blockIdx.x >= nf8 * SUB) {
-        const int vb = blockIdx.x - nf8 * SUB, vt = xcd_tile(vb, d.n_vtiles);
-        double ks[KV_N] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (vt < d.n_vtiles) q_lambda_vertex_tile<false, BLOCK, true>(d, vt, sz, cd, cr, tau, &ka, ks);
-        block_sum<KV_N>(ks, lds);
-        if (threadIdx.x == 0) store_fused<KV_N>(ks, KV_SLOT, 0, kf.part_v, kf.nv, vb);
-        return;
-    }
-    double kt[KF_N] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    const int tile = xcd_tile(blockIdx.x % nf8, d.n_ftiles);
-    if (tile < d.n_ftiles) {
-        const int e = ((blockIdx.x / nf8) * BLOCK + threadIdx.x) * 2;
-        const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
-        if (row < 3 * d.F && t < d.nl) {
-            const int f = row / 3, c = row - 3 * f;
-            ql2_lane<ZMODE, false, false, true>(d, f, c, t, sz * INV_SQRT3, 1.0 + 2.0 * sz * sz, 1.0 + sz * sz, tau, nullptr, sz, kt);
-        }
-    }
-    block_sum<KF_N>(kt, lds);
-    if (threadIdx.x == 0) store_fused<KF_N>(kt, KF_SLOT, N_VSUMS, kf.part_f, kf.nf, blockIdx.x);
 }
 
 // Step 0 of is_palm = True: (A, B, lambda_c) from the current multipliers and the stored z_mid; nothing else moves.
@@ -1246,43 +1230,41 @@ int launch_q_lambda_only(Ctx *c) {
 }
 
 // steps 2+3 as launch_q_lambda_mult would run them can divide the dual arrays as they read them (the carry kernels)
-bool ql_divides(const Ctx *c, int zmid_mode) { return carry_possible(c) && c->step_carry && zmid_mode >= 1; }
+bool ql_divides(const Ctx *c, int zmid_mode) {
+    return carry_possible(c) && ((c->step_carry && zmid_mode >= 1) || (c->step_kkt && zmid_mode == 1 && c->kkt_fused.part_v && !c->d.slab));
+}
 
 int launch_q_lambda_mult(Ctx *c, int zmid_mode, double dv) {
     const dots_params &p = c->prm;
     const int nf8 = xcd_grid(c->d.n_ftiles), nv8 = xcd_grid(c->d.n_vtiles);
     const double cd = p.const_d, cr = p.congestion * p.r;
     c->carry_valid = c->kkt_fused_valid = 0;
-    // DOTS_STEP_KKT_SUMS: the launch also leaves the sums of the KKT conditions it can form from its registers (kkt_fused)
-    const bool kkt = c->step_kkt && zmid_mode >= 1 && c->kkt_fused.part_v && c->ql_two && c->d.TP >= 4 && !c->d.slab;
+    // DOTS_STEP_KKT_SUMS: the launch also leaves the sums of the KKT conditions it can form from its registers (kkt_fused) and the
+    // per-corner gather of Dual(alpha) (cn_e); it takes the carry mapping (whole triangles per workgroup) whether or not the next
+    // iteration's gathers are wanted (emit)
+    const bool kkt = c->step_kkt && zmid_mode == 1 && c->kkt_fused.part_v && carry_possible(c) && !c->d.slab;
     const KktArgs ka{KKT_FUSED_MASK, p.r, p.scale_z, p.const_d, p.congestion, p.prim_scale, p.dual_scale, p.boundary_scale};
     KktFused kf = c->kkt_fused;
     kf.nv = nv8;
-    if (carry_possible(c) && c->step_carry && zmid_mode >= 1) {      // ... and the next iteration's gathers are formed here (k_q_lambda_mult_carry)
+    const bool carry = carry_possible(c) && c->step_carry && zmid_mode >= 1;
+    if (carry || kkt) {      // k_q_lambda_mult_carry
         const int tw = (2 * CARRY_NB / c->d.TP) / 3, n_fwg = xcd_grid((c->d.F + tw - 1) / tw);
         const dim3 g(n_fwg + nv8);
         kf.nf = n_fwg;
         const bool k = kkt && nv8 <= c->kkt_fused_cap_v && n_fwg <= c->kkt_fused_cap_f;
+        const int emit = (carry ? 1 : 0) | (k ? 2 : 0);
 #define CARRY_LAUNCH(Z, K)                                                                                                                                     \
     do {                                                                                                                                                     \
-        if (dv != 0.0) hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, true>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, dv); \
-        else hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, false>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, 1.0);        \
+        if (dv != 0.0) hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, true>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, dv, emit); \
+        else hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, false>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, 1.0, emit);        \
     } while (0)
         if (zmid_mode == 2) CARRY_LAUNCH(2, false);
         else if (k) CARRY_LAUNCH(1, true);
         else CARRY_LAUNCH(1, false);
 #undef CARRY_LAUNCH
         DOTS_HIP(hipGetLastError());
-        c->carry_valid = 1;
-        if (k && zmid_mode == 1) { c->kkt_fused = kf; c->kkt_fused_valid = 1; }
-        return 0;
-    }
-    if (kkt && zmid_mode == 1 && nv8 <= c->kkt_fused_cap_v && nf8 * (TILE_ELEMS / (2 * BLOCK)) <= c->kkt_fused_cap_f) {
-        kf.nf = nf8 * (TILE_ELEMS / (2 * BLOCK));
-        hipLaunchKernelGGL((k_q_lambda_mult_triangle2_kkt<1>), dim3(kf.nf + nv8), dim3(BLOCK), 0, c->stream, c->d, p.scale_z, p.tau, nf8, cd, cr, ka, kf);
-        DOTS_HIP(hipGetLastError());
-        c->kkt_fused = kf;
-        c->kkt_fused_valid = 1;
+        c->carry_valid = carry ? 1 : 0;
+        if (k) { c->kkt_fused = kf; c->kkt_fused_valid = 1; }
         return 0;
     }
     if (c->ql_two && c->d.TP >= 4) {      // two nodes per lane (16-byte accesses): k_q_lambda_mult_triangle2
@@ -1562,7 +1544,7 @@ void preload_alm_kernels() {
         (const void *)k_q_lambda_mult_triangle2<0>, (const void *)k_q_lambda_mult_triangle2<1>, (const void *)k_q_lambda_mult_triangle2<2>,
         (const void *)k_q_lambda_mult_carry<1>, (const void *)k_q_lambda_mult_carry<2>, (const void *)k_q_lambda_mult_carry<1, true>,
         (const void *)k_q_lambda_mult_carry<1, false, true>, (const void *)k_q_lambda_mult_carry<2, false, true>, (const void *)k_q_lambda_mult_carry<1, true, true>,
-        (const void *)k_q_lambda_mult_triangle2_kkt<1>,
+
         (const void *)k_divide_five, (const void *)k_scale, (const void *)k_divide, (const void *)k_rebuild_mu, (const void *)k_rebuild_E,
     };
     hipFuncAttributes a;

@@ -1160,7 +1160,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         for (const FrontNode &nd : nodes) srows += (int64_t)nd.b * nd.b;
         const double per = 8.0 * (double)d.TP;
         const double factor_b = per * (double)all_entries, work_b = h->values ? 0.0 : per * (double)(h->n_entries + srows);
-        const double carry_b = (c->d.TP <= 128 && c->carry_arrays) ? 8.0 * 9.0 * (double)c->d.F * (double)c->d.TP : 0.0;
+        const double carry_b = (c->d.TP <= 128 && c->carry_arrays) ? 8.0 * (c->shard_stride == 0 ? 12.0 : 9.0) * (double)c->d.F * (double)c->d.TP : 0.0;
         size_t free_b = 0, total_b = 0;
         DOTS_HIP(hipMemGetInfo(&free_b, &total_b));
         double budget = 0.97 * (double)free_b;

@@ -406,6 +406,53 @@ __device__ __forceinline__ void kkt_triangle_body2(const Dev &d, const KktArgs &
     }
 }
 
+// Dual(alpha) (solver_socp.py:466-482) from the per-corner sums sum_xyz area * hat * E that the last steps-2+3 launch left in cn_e
+// (corner-list order: a vertex's rows are contiguous): two nodes per lane, no walk over E.  The expression of kkt_vertex_body2;
+// the corner sums are added in list order (a corner's xyz share first: the residual agrees with that body to rounding).
+__global__ __launch_bounds__(BLOCK) void k_kkt_dual_alpha_carried(Dev d, KktArgs a, int nblk, double *__restrict__ part) {
+    __shared__ double lds[4];
+    constexpr int SUB = TILE_ELEMS / (2 * BLOCK);
+    const int G8 = nblk / SUB, bid = blockIdx.x;
+    const int tile = xcd_tile(bid % G8, d.n_vtiles);
+    double s[1] = {0.0};
+    const int e = ((bid / G8) * BLOCK + threadIdx.x) * 2;
+    const int v = tile * d.VT + (e >> d.tp_shift), t = e & (d.TP - 1);
+    if (tile < d.n_vtiles && v < d.V && t < d.nl) {
+        const double ih = 1.0 / d.h, m = d.mass_v[v];
+        const int iv = idxV(d, v, t);
+        const D2 mu = ld2(d.mu + iv);
+        const double mum1 = t > 0 ? d.mu[iv - 1] : 0.0;
+        double dsx[2] = {0.0, 0.0};
+        const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
+        const double *__restrict__ g = d.cn_e + t;
+        for (int j = j0; j < j1; j += 2) {
+            const D2 g0 = ld2(g + ((int64_t)j << d.tp_shift)), g1 = ld2(g + ((int64_t)min(j + 1, j1 - 1) << d.tp_shift));
+            dsx[0] += g0.v[0];
+            dsx[1] += g0.v[1];
+            if (j + 1 < j1) {
+                dsx[0] += g1.v[0];
+                dsx[1] += g1.v[1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tu = t + u;
+            if (tu >= d.nl) continue;
+            double x = 0.0;
+            if (tu < d.ni) x += mu.v[u] * m;
+            if (tu > 0) x -= (u == 0 ? mum1 : mu.v[0]) * m;
+            x *= ih;
+            x -= dsx[u];
+            if (tu == 0) x -= a.bs * d.mu0[v] / (a.r * d.h);
+            if (tu == d.T) x += a.bs * d.mu1[v] / (a.r * d.h);
+            const double aux = (a.r * d.h) * x / m;
+            s[0] += aux * aux * m;
+        }
+    }
+    block_sum<1>(s, lds);
+    if (threadIdx.x == 0) part[bid] = s[0];
+}
+
 // Workgroups [0, nv): the vertex sums (first: their corner walks are the longer chain), [nv, nv + nf): the triangle sums.
 // One launch for both on the iterations that read residuals back (independent sums: two latency-bound kernels overlap).
 template <bool TWO>
@@ -592,7 +639,8 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
             if (v_slot) { src.p[i] = kf.part_v + (int64_t)i * kf.nv; src.n[i] = kf.nv; have[i] = true; }
             if (f_slot) { src.p[i] = kf.part_f + (int64_t)(i - N_VSUMS) * kf.nf; src.n[i] = kf.nf; have[i] = true; }
         }
-        if (nv) {
+        if (nv && two && d.cn_e) hipLaunchKernelGGL(k_kkt_dual_alpha_carried, dim3(nv), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials + (int64_t)V_DUALAUX2 * nv);
+        else if (nv) {
             if (two) hipLaunchKernelGGL(k_kkt_sums<true>, dim3(nv), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
             else hipLaunchKernelGGL(k_kkt_sums<false>, dim3(nv), dim3(BLOCK), 0, c->stream, d, a, nv, d.partials, part_f);
         }
@@ -610,8 +658,19 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
         // right-hand side (it reads only what the next dots_step would read; dots_api.hip: check() drops it if anything changes)
         if (c->rhs_ahead_armed) {
             c->rhs_ahead_armed = 0;
-            if ((rc = launch_rhs(c))) return rc;
-            c->rhs_ahead = 1;
+            if (rhs_takes_soc(c) && c->zf_alt) {      // ... and its cone projection, into the alternate buffers (a dropped launch leaves the state as it is)
+                Dev keep = c->d;
+                c->d.zf = c->zf_alt;
+                c->d.ze = c->ze_alt;
+                c->d.lamc = c->lamc_alt;
+                rc = launch_rhs(c, true);
+                c->d = keep;
+                if (rc) return rc;
+                c->rhs_ahead = 2;
+            } else {
+                if ((rc = launch_rhs(c))) return rc;
+                c->rhs_ahead = 1;
+            }
         }
         rc = wait_mail(c, seq, N_SUMS);
     } else {
@@ -812,7 +871,7 @@ int norm_square(Ctx *c, int id, int part, double *out) {
 }
 
 void preload_kkt_kernels() {      // (see preload_alm_kernels)
-    const void *fns[] = {(const void *)k_kkt_sums<true>, (const void *)k_kkt_sums<false>, (const void *)k_reduce_slots, (const void *)k_mail_sums, (const void *)k_reduce_mail,
+    const void *fns[] = {(const void *)k_kkt_sums<true>, (const void *)k_kkt_sums<false>, (const void *)k_kkt_dual_alpha_carried, (const void *)k_reduce_slots, (const void *)k_mail_sums, (const void *)k_reduce_mail,
                          (const void *)k_objective, (const void *)k_norm};
     hipFuncAttributes a;
     for (const void *f : fns) (void)hipFuncGetAttributes(&a, f);

@@ -79,15 +79,13 @@ class AlmSolver:
         self.untimed_steps = 0          # iterations whose phases were not timed (run_history.steps_time is estimated from the others)
         self.quiet_steps = 0            # iterations after which nothing was read back
         self._timed_in_flight = []      # kinds of the timed iterations whose events have not been collected yet (one entry per slot)
-        # the right-hand side of the iteration after a read-back may be enqueued ahead (iterate(); DOTS_RHS_AHEAD=0 never, =2 always).
-        # Only on small problems: the iteration that follows runs its projection apart from its right-hand side, which costs more
-        # than the idle time it fills once the kernels are bandwidth-bound, and one launch more from T + 1 = 64 on (measured on the
-        # driver's 20 steps: plane20 +2.5 %, knot +1.5 %, sphere10k +0.3 %, knot63 -0.7 %, torus100k -2.5 %)
+        # the right-hand side + cone projection of the iteration after a read-back may be enqueued ahead (iterate(); DOTS_RHS_AHEAD=0
+        # never).  Round 2 only did so on small problems (the projection then ran apart from the right-hand side: one launch more);
+        # the projection now rides in the launch ahead, its results in alternate buffers until the step takes them: the same launch
+        # the iteration would start with, only earlier -- on for every size
         ahead = env_choice("DOTS_RHS_AHEAD", ("0", "1", "2"), "1")
         self._rhs_ahead_ok = (direct and time_slab is None and not self.is_palm and not check_kkt_step_by_step
-                              and not is_constant_scaling and ahead != "0"
-                              and (ahead == "2" or (int(n_time) + 1 < 64
-                                                    and np.asarray(geometry["vertices"]).shape[0] * (int(n_time) + 1) <= 200_000)))
+                              and not is_constant_scaling and ahead != "0")
         self._rhs_ahead = False
         self._carry = False             # DOTS_STEP_CARRY for the next device step (iterate())
         self._fused_kkt = False         # the last device step formed the KKT sums it holds in registers (DOTS_STEP_KKT_SUMS)
