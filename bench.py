@@ -91,18 +91,28 @@ def git_commit():
         return None
 
 
-def iteration_bytes(T, V, F, solve_bytes, z_mid_stored=False):
-    """Algorithmic bytes ONE iteration of the implemented algorithm moves, N = (T+1) V:
-        right-hand side        A, lambda_c, mu r (3TV); B, E r (6(T+1)F); b-hat w (N)
-        cone projection        beta_mid r (18TF); B r (3(T+1)F); A, beta_fst, beta_end r, z_fst, z_end, lambda w (6TV)
+def iteration_bytes(T, V, F, solve_bytes, z_mid_stored=False, carried=True):
+    """Algorithmic bytes ONE iteration of the implemented algorithm moves, N = (T+1) V.
+    ``carried`` (round 4, the default path of the direct solver up to a time pitch of 128: DOTS_STEP_CARRY): steps 2+3 leave per-corner
+    sums (cn_sq: 6TF values, cn_g: 3(T+1)F) and the right-hand side / projection stream those instead of B, E and beta_mid:
+        right-hand side        A, lambda_c, mu r (3TV); cn_g r (3(T+1)F); b-hat w (N)
+        cone projection        cn_sq r (6TF); A, beta_fst, beta_end r, z_fst, z_end, lambda w (6TV)
         solve                  the factor twice + four vector passes (``solve_bytes``)
         inverse transform      2N
-        steps 2+3, triangles   beta_mid r+w (36TF); B, E r+w (12(T+1)F); phi r (N); cone multiplier r (TV)
+        steps 2+3, triangles   beta_mid r+w (36TF); B, E r+w (12(T+1)F); phi r (N); cone multiplier r (TV); cn_sq, cn_g w (6TF + 3(T+1)F)
         steps 2+3, vertices    11TV
+    not carried (rounds 1-3; today the iteration after a penalty update and time pitches above 128):
+        right-hand side        ... B, E r (6(T+1)F) instead of cn_g
+        cone projection        beta_mid r (18TF); B r (3(T+1)F) instead of cn_sq
+        steps 2+3              without the cn_* stores
     z_mid (18TF) is written only on the iterations whose results are read back, never read."""
     N = (T + 1) * V
-    words = (3 * T * V + 6 * (T + 1) * F + N) + (18 * T * F + 3 * (T + 1) * F + 6 * T * V) + 2 * N \
-        + (36 * T * F + 12 * (T + 1) * F + N + T * V) + 11 * T * V
+    if carried:
+        words = (3 * T * V + 3 * (T + 1) * F + N) + (6 * T * F + 6 * T * V) + 2 * N \
+            + (36 * T * F + 12 * (T + 1) * F + N + T * V + 6 * T * F + 3 * (T + 1) * F) + 11 * T * V
+    else:
+        words = (3 * T * V + 6 * (T + 1) * F + N) + (18 * T * F + 3 * (T + 1) * F + 6 * T * V) + 2 * N \
+            + (36 * T * F + 12 * (T + 1) * F + N + T * V) + 11 * T * V
     if z_mid_stored:
         words += 18 * T * F
     return 8.0 * words + solve_bytes
@@ -245,10 +255,11 @@ def solve_roofline(alm, V, n_time):
 
 
 def whole_iteration(T, V, F, solve_bytes, ms_per_step, label):
-    b = iteration_bytes(T, V, F, solve_bytes)
+    b = iteration_bytes(T, V, F, solve_bytes, carried=T + 1 <= 128)
     return {"algorithmic_bytes": b, "achieved": b / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s", "frac": b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "over": label, "note": "bytes the implemented iteration moves when z_mid is not materialised (bench.py: iteration_bytes); "
-                                   "KKT evaluations and penalty updates inside the window are not counted as bytes"}
+            "over": label, "note": "bytes the implemented iteration moves when z_mid is not materialised and the next iteration's gathers are carried "
+                                   "(bench.py: iteration_bytes; round 3's iteration moved 72 T F bytes more); KKT evaluations and penalty updates inside the "
+                                   "window are not counted as bytes"}
 
 
 def time_to_tol(args, wl, geom, local_rank):

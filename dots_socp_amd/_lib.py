@@ -124,7 +124,7 @@ SLAB_SIZES = {"vertex_halo": 0, "b_chunk": 1, "x_chunk": 2, "triangle_halo": 3}
 # not in this list, or a value outside a switch's domain, is an error: a typo must not silently select the default.
 KNOWN_ENV = {
     # read by the library (csrc/dots_api.hip: env_int)
-    "DOTS_CG_STAGE_LDS", "DOTS_MG_TAIL_ROWS", "DOTS_SOC_WITH_RHS", "DOTS_QL_TWO", "DOTS_KKT_TWO", "DOTS_RHS_TWO", "DOTS_RHS_TILES", "DOTS_CARRY", "DOTS_LAZY_DIV", "DOTS_MEM_BUDGET", "DOTS_SPIN_FETCH",
+    "DOTS_CG_STAGE_LDS", "DOTS_MG_TAIL_ROWS", "DOTS_SOC_WITH_RHS", "DOTS_QL_TWO", "DOTS_KKT_TWO", "DOTS_RHS_TWO", "DOTS_RHS_TILES", "DOTS_CARRY", "DOTS_CARRY_MIN", "DOTS_LAZY_DIV", "DOTS_MEM_BUDGET", "DOTS_SPIN_FETCH",
     "DOTS_FRONT_VEC2", "DOTS_FRONT_RB", "DOTS_FRONT_ROWS", "DOTS_FRONT_XCD", "DOTS_FRONT_TUNE", "DOTS_FRONT_CFG", "DOTS_MAIL_TEST_DROP",
     "DOTS_MAIL_SPINS", "DOTS_ND_PCA_MIN",
     # read by the host side
@@ -161,7 +161,7 @@ def library_path() -> str:
     return LIB_PATH
 
 
-def _torch_runtime_first():
+def _torch_runtime_first(init=True):
     """PyTorch-ROCm wheels bundle their own copy of the HIP runtime under the same SONAME (libamdhip64.so.7) this library
     links against, so a process ends up with ONE runtime: whichever copy is loaded first.  Loaded after torch, this library
     runs on torch's copy (streams, events and device pointers are then interchangeable between the two, which distributed.py
@@ -175,7 +175,7 @@ def _torch_runtime_first():
     torch = sys.modules.get("torch")
     if torch is None and env_choice("DOTS_TORCH_FIRST", ("0", "1"), "1") == "1" and importlib.util.find_spec("torch") is not None:
         import torch
-    if torch is None:
+    if torch is None or not init:
         return
     try:
         if torch.cuda.is_available() and not torch.cuda.is_initialized():
@@ -184,10 +184,19 @@ def _torch_runtime_first():
         pass
 
 
-def load():
-    """Load the shared library (once) and declare the signatures."""
-    global _lib
+_runtime_ready = False
+
+
+def load(host_only=False):
+    """Load the shared library (once) and declare the signatures.  ``host_only``: the caller uses host entry points only
+    (dots_assemble, dots_patch_order, dots_tree_*, dots_symbolic_*): torch is still imported first (one copy of the HIP runtime per
+    process, see _torch_runtime_first) but the GPU runtime is not initialised -- a process that only assembles operators, or a parent
+    that is about to spawn ranks, stays clear of the device."""
+    global _lib, _runtime_ready
     if _lib is not None:
+        if not host_only and not _runtime_ready:
+            _torch_runtime_first(init=True)
+            _runtime_ready = True
         return _lib
     check_environment()
     if not os.path.exists(LIB_PATH):
@@ -195,7 +204,8 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m dots_socp_amd.build` (hipcc, gfx950). "
             "dots_socp_amd has no CPU fallback."
         )
-    _torch_runtime_first()
+    _torch_runtime_first(init=not host_only)
+    _runtime_ready = not host_only
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the host

@@ -403,6 +403,14 @@ class ShardedAlmSolver(AlmSolver):
             self._order(ctx_waits=True)
             return dt + time.perf_counter() - t1
 
+        try:
+            self._stages_and_exchanges(dev, comm, buf, wait, timed, kind, exchange, events)
+        except Exception:
+            self._timed_in_flight.clear()      # (see AlmSolver._device_step: the ring and these lists no longer match)
+            self._comm_events.clear()
+            raise
+
+    def _stages_and_exchanges(self, dev, comm, buf, wait, timed, kind, exchange, events):
         t_comm = 0.0
         stats = [dev.slab_stage(0, wait=wait)]
         t_comm += exchange(lambda: comm.exchange(self.n_active, fwd=(buf["send_x"], buf["recv_x"]), bwd=(buf["send_nsq"], buf["recv_nsq"]), sync=wait))

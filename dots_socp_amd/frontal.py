@@ -147,7 +147,7 @@ def _nested_dissection_native(indptr, indices, coords, leaf):
 
     from . import _lib
 
-    lib = _lib.load()
+    lib = _lib.load(host_only=True)
     ip = np.ascontiguousarray(indptr, dtype=np.int32)
     ix = np.ascontiguousarray(indices, dtype=np.int32)
     xyz = np.ascontiguousarray(coords, dtype=np.float64)
@@ -172,7 +172,7 @@ def symbolic_native(diss: Dissection, indptr, indices):
 
     from . import _lib
 
-    lib = _lib.load()
+    lib = _lib.load(host_only=True)
     ip = np.ascontiguousarray(indptr, dtype=np.int32)
     ix = np.ascontiguousarray(indices, dtype=np.int32)
     order = np.ascontiguousarray(diss.order, dtype=np.int64)

@@ -94,7 +94,7 @@ def assemble_native(vertices, triangles):
     v = np.ascontiguousarray(vertices, dtype=np.float64)
     t = np.ascontiguousarray(triangles, dtype=np.int32)
     V, F = v.shape[0], t.shape[0]
-    lib = _lib.load()
+    lib = _lib.load(host_only=True)      # host code of the library: no GPU runtime is initialised for it
     h = C.c_void_p()
     f64, i32 = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     _lib.check(lib.dots_assemble(V, F, v.ctypes.data_as(f64), t.ctypes.data_as(i32), C.byref(h)), "dots_assemble")
@@ -190,14 +190,25 @@ def patch_order(vertices, unit=16):
 
     v = np.ascontiguousarray(vertices, dtype=np.float64)
     out = np.empty(v.shape[0], dtype=np.int32)
-    lib = _lib.load()
+    lib = _lib.load(host_only=True)
     _lib.check(lib.dots_patch_order(v.shape[0], v.ctypes.data_as(C.POINTER(C.c_double)), int(unit), out.ctypes.data_as(C.POINTER(C.c_int32))),
                "dots_patch_order")
     return out
 
 
-def build_plan(n_time, geometry, reorder=True, nd_leaf=16) -> DevicePlan:
-    """``reorder``: True / "rcm" reverse Cuthill-McKee, "nd" nested dissection (direct solver), False none."""
+def assemble_reference(vertices, triangles):
+    """The same six results from the numpy reference functions of this module (no library needed: host-only tools and tests)."""
+    V = vertices.shape[0]
+    area, hat = hat_gradients(vertices, triangles)
+    cptr, cidx = corner_lists(V, triangles)
+    mass = np.zeros(V)
+    np.add.at(mass, triangles.reshape(-1), np.repeat(area, 3) / 3.0)
+    return area, hat, mass, cptr.astype(np.int32), cidx.astype(np.int32), stiffness_matrix(V, triangles, area, hat)
+
+
+def build_plan(n_time, geometry, reorder=True, nd_leaf=16, native=True) -> DevicePlan:
+    """``reorder``: True / "rcm" reverse Cuthill-McKee, "nd" nested dissection (direct solver), False none.
+    ``native``: the library's host assembly (dots_assemble; the product path) or the numpy reference functions."""
     vertices = np.asarray(geometry["vertices"], dtype=np.float64)
     triangles = np.asarray(geometry["triangles"]).astype(np.int64)
     mu0 = np.asarray(geometry["mu0"], dtype=np.float64)
@@ -222,7 +233,7 @@ def build_plan(n_time, geometry, reorder=True, nd_leaf=16) -> DevicePlan:
         triangles = inv[triangles[perm_f]]
         mu0, mu1 = mu0[perm_v], mu1[perm_v]
 
-    area, hat, mass, cptr, cidx, K = assemble_native(vertices, triangles)
+    area, hat, mass, cptr, cidx, K = assemble_native(vertices, triangles) if native else assemble_reference(vertices, triangles)
     if not np.all(area > 0):
         raise ValueError("degenerate triangle (zero area)")
     if not np.all(mass > 0):

@@ -39,6 +39,7 @@ PRIMAL = ("phi", "A", "B", "lambda_c")
 Z_VARS = ("z_fst", "z_mid", "z_end")
 DUAL_QE = ("mu", "E")
 BETAS = ("beta_fst", "beta_mid", "beta_end")
+CARRY_MIN_NODES = 0       # space-time nodes from which quiet iterations carry the next iteration's gathers (DOTS_CARRY_MIN)
 DEFAULT_CG_TOL = 1e-8     # parity study: profiles/studies/cg_tol_parity.txt (cost within 1e-9 of the reference, budget 1e-6)
 
 
@@ -88,6 +89,11 @@ class AlmSolver:
                               and not is_constant_scaling and ahead != "0")
         self._rhs_ahead = False
         self._carry = False             # DOTS_STEP_CARRY for the next device step (iterate())
+        # ... which pays where the iteration is bandwidth-bound: below DOTS_CARRY_MIN space-time nodes (V (T + 1)) the launches are
+        # latency-bound and the bytes saved in the right-hand side / projection only balance what the exchange through LDS costs
+        # steps 2+3 (A/B of the round: DESIGN.md section 5)
+        nodes = int(np.asarray(geometry["vertices"]).shape[0]) * (int(n_time) + 1)
+        self._carry_ok = direct and not self.is_palm and nodes >= int(env_choice("DOTS_CARRY_MIN", None, str(CARRY_MIN_NODES), integer=(0, 1 << 40)))
         self._fused_kkt = False         # the last device step formed the KKT sums it holds in registers (DOTS_STEP_KKT_SUMS)
         if direct and reorder is True:
             reorder = "nd"      # the elimination order of the factor doubles as the locality numbering
@@ -333,7 +339,13 @@ class AlmSolver:
             self.dev.step_flags(skip_z_mid=quiet and not self.is_palm, palm=self.is_palm, rhs_ahead=self._rhs_ahead and not quiet, timed=timed,
                                 carry=self._carry, kkt_sums=not quiet)
             self._fused_kkt = not quiet
-            self.dev.step(1, wait=False)
+            try:
+                self.dev.step(1, wait=False)
+            except Exception:
+                # the library gave the timing slot of a failed step back: what this side still expects of the ring can no longer
+                # be matched to kinds -- drop it, so that the error that surfaces is the step's own
+                self._timed_in_flight.clear()
+                raise
             if timed:
                 self._timed_in_flight.append(kind)
             else:
@@ -398,7 +410,7 @@ class AlmSolver:
         # The next iteration starts from the state this one leaves unless the penalty is updated in between (known from the schedule;
         # a z rescaling or a stop simply drop what was carried): steps 2+3 then also store the per-corner sums that iteration's
         # right-hand side and cone projection would gather from B, E and beta_mid (DOTS_STEP_CARRY: one pass over beta_mid less).
-        self._carry = self.direct and not self.is_palm and it + 1 < self.nit and not params.peek_adjust(it)
+        self._carry = self._carry_ok and it + 1 < self.nit and not params.peek_adjust(it)
         self._device_step(quiet)                                                # steps 1-3 (:674-722)
 
         adjust = params.is_to_adjust(it) or is_time_used_up

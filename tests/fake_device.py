@@ -59,7 +59,7 @@ class FakeDeviceProblem:
         self._lu = {}
         from dots_socp_amd.geometry import build_plan
 
-        real = build_plan(n_time, geometry, reorder=False)       # hat gradients / areas for the closed forms of the driver
+        real = build_plan(n_time, geometry, reorder=False, native=False)       # hat gradients / areas for the closed forms of the driver
         self.plan = types.SimpleNamespace(perm_vert=None, mass_vert=s.mass_v, mu0=self.mu0, mu1=self.mu1, area_tri=real.area_tri,
                                           hat_grad=real.hat_grad, triangles=real.triangles)
         self.v2c = O.corner_maps(s.V, s.tri, s.area_f)[2]          # (3F, V) 0/1

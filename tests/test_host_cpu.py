@@ -396,6 +396,19 @@ def test_environment_switches_are_validated(monkeypatch):
         frontal.plan_bands(None, None, None, 32) if False else _lib.env_choice("DOTS_FRONT_TOPINV", ("auto", "0", "1"), "auto")
 
 
+def test_plan_from_the_numpy_reference_functions_equals_the_native_one():
+    """geometry.build_plan(native=False) (what host-only tools and the fake device of the gloo tests use: no library needed)
+    gives the arrays of the library's dots_assemble."""
+    from dots_socp_amd import geometry, meshes
+
+    geom, _ = meshes.example("sphere", level=2)
+    a, b = geometry.build_plan(7, geom, reorder=False, native=True), geometry.build_plan(7, geom, reorder=False, native=False)
+    for name in ("triangles", "corner_ptr", "corner_idx", "lap_rowptr", "lap_col"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    for name in ("hat_grad", "area_tri", "mass_vert", "lap_val"):
+        assert np.allclose(getattr(a, name), getattr(b, name), rtol=1e-12, atol=1e-15), name
+
+
 def test_sampled_step_timers_scale_to_all_iterations():
     """control.SampledStepTimers: per kind of iteration, the first `first` timed iterations count exactly and the others at the
     median of the periodic samples; a slow warm-up iteration is NOT scaled to the whole run; records of one iteration that
