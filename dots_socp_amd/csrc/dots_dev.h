@@ -438,6 +438,39 @@ __device__ __forceinline__ int64_t idxM(const Dev &d, int fk, int s, int c, int 
 struct D2 { double v[2]; };
 __device__ __forceinline__ D2 ld2(const double *p) { const double2 t = *reinterpret_cast<const double2 *>(p); return D2{{t.x, t.y}}; }
 __device__ __forceinline__ void st2(double *p, const D2 &x) { *reinterpret_cast<double2 *>(p) = make_double2(x.v[0], x.v[1]); }
+// the same with a streaming hint (non-temporal): data written once and read once by the next launch (the carried per-corner sums)
+// or not read at all in the loop (z_mid on read-back iterations) should not displace the factor and beta_mid from the caches.
+// A/B on one box (-DDOTS_CARRY_NT=0 against the default): knot 9 720-10 020 -> 10 160-10 210 it/s, sphere10k 4 795-4 813 -> 4 936-4 983,
+// torus100k 619 -> 631-646, knot63 unchanged (profiles/studies/r04_nontemporal.txt)
+#ifndef DOTS_CARRY_NT
+#define DOTS_CARRY_NT 1
+#endif
+typedef double dots_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ D2 ld2_nt(const double *p) {
+#if DOTS_CARRY_NT
+    const dots_d2v t = __builtin_nontemporal_load(reinterpret_cast<const dots_d2v *>(p));
+    return D2{{t.x, t.y}};
+#else
+    return ld2(p);
+#endif
+}
+__device__ __forceinline__ double ld1_nt(const double *p) {
+#if DOTS_CARRY_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st2_nt(double *p, const D2 &x) {
+#if DOTS_CARRY_NT
+    dots_d2v t;
+    t.x = x.v[0];
+    t.y = x.v[1];
+    __builtin_nontemporal_store(t, reinterpret_cast<dots_d2v *>(p));
+#else
+    st2(p, x);
+#endif
+}
 // slab predicates for local column t
 __device__ __forceinline__ bool first_node(const Dev &d, int t) { return d.t0 + t == 0; }       // global node 0
 __device__ __forceinline__ bool last_node(const Dev &d, int t) { return d.t0 + t == d.T; }      // global node T

@@ -71,8 +71,8 @@ __device__ __forceinline__ void soc_element(const Dev &d, int v, int t, double s
 #pragma unroll
             for (int i = 0; i < CARRY_BATCH; ++i) {
                 const int64_t row = ((int64_t)(2 * min(j + i, j1 - 1)) << d.tp_shift) + t;
-                q0[i] = d.cn_sq[row];
-                q1[i] = d.cn_sq[row + d.TP];
+                q0[i] = ld1_nt(d.cn_sq + row);
+                q1[i] = ld1_nt(d.cn_sq + row + d.TP);
             }
 #pragma unroll
             for (int i = 0; i < CARRY_BATCH; ++i) {
@@ -148,8 +148,8 @@ __device__ __forceinline__ void soc_element2(const Dev &d, int v, int t, double 
 #pragma unroll
             for (int i = 0; i < CARRY_BATCH; ++i) {
                 const int64_t row = (int64_t)(2 * min(j + i, j1 - 1)) << d.tp_shift;
-                q0[i] = ld2(q + row);
-                q1[i] = ld2(q + row + d.TP);
+                q0[i] = ld2_nt(q + row);
+                q1[i] = ld2_nt(q + row + d.TP);
             }
 #pragma unroll
             for (int i = 0; i < CARRY_BATCH; ++i) {
@@ -347,7 +347,7 @@ __device__ __forceinline__ double rhs_value(const Dev &d, int v, int t, double r
         for (int j = jc0; j < jc1; j += CARRY_BATCH) {
             double gj[CARRY_BATCH];
 #pragma unroll
-            for (int i = 0; i < CARRY_BATCH; ++i) gj[i] = d.cn_g[((int64_t)min(j + i, jc1 - 1) << d.tp_shift) + t];
+            for (int i = 0; i < CARRY_BATCH; ++i) gj[i] = ld1_nt(d.cn_g + ((int64_t)min(j + i, jc1 - 1) << d.tp_shift) + t);
 #pragma unroll
             for (int i = 0; i < CARRY_BATCH; ++i) {
                 if (j + i >= jc1) break;
@@ -457,7 +457,7 @@ __device__ __forceinline__ void rhs_value2(const Dev &d, int v, int t, double r,
         for (int j = jc0; j < jc1; j += CARRY_BATCH) {
             D2 gj[CARRY_BATCH];
 #pragma unroll
-            for (int i = 0; i < CARRY_BATCH; ++i) gj[i] = ld2(g + ((int64_t)min(j + i, jc1 - 1) << d.tp_shift));
+            for (int i = 0; i < CARRY_BATCH; ++i) gj[i] = ld2_nt(g + ((int64_t)min(j + i, jc1 - 1) << d.tp_shift));
 #pragma unroll
             for (int i = 0; i < CARRY_BATCH; ++i) {
                 if (j + i >= jc1) break;
@@ -982,8 +982,8 @@ __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, doub
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 // (entries of intervals that do not exist are stored as the zeros computed above; their slots are never read as data)
-                st2(d.zm + idxM(d, f * 3 + k, 0, c, t), z0[k]);
-                st2(d.zm + idxM(d, f * 3 + k, 1, c, t - 1), z1[k]);
+                st2_nt(d.zm + idxM(d, f * 3 + k, 0, c, t), z0[k]);      // (not read again inside the loop)
+                st2_nt(d.zm + idxM(d, f * 3 + k, 1, c, t - 1), z1[k]);
             }
         }
         st2(d.B + ie, Bn);
@@ -1202,14 +1202,14 @@ __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carr
         const int j = d.cpos[f * 3 + c];
 #endif
         if (emit & 1) {
-            st2(d.cn_sq + ((int64_t)(2 * j) << d.tp_shift) + t, D2{{q[0], q[1]}});
-            st2(d.cn_sq + ((int64_t)(2 * j + 1) << d.tp_shift) + t, D2{{q[3], t + 2 < d.TP ? nxt : 0.0}});
-            st2(d.cn_g + ((int64_t)j << d.tp_shift) + t, D2{{q[4], q[5]}});
+            st2_nt(d.cn_sq + ((int64_t)(2 * j) << d.tp_shift) + t, D2{{q[0], q[1]}});
+            st2_nt(d.cn_sq + ((int64_t)(2 * j + 1) << d.tp_shift) + t, D2{{q[3], t + 2 < d.TP ? nxt : 0.0}});
+            st2_nt(d.cn_g + ((int64_t)j << d.tp_shift) + t, D2{{q[4], q[5]}});
             if (t == 0 && has_prev_interval(d, 0)) d.cn_lo[j] = q[2];      // (time slab: the half of the previous slab's last interval formed here)
         }
         if (KKT && (emit & 2)) {
             const double *x0 = xs + (CARRY_VALUES + c * 2) * CARRY_NB + t0, *x1 = x0 + CARRY_NB;
-            st2(d.cn_e + ((int64_t)j << d.tp_shift) + t, D2{{sum3(x0[0], x0[L], x0[2 * L]), sum3(x1[0], x1[L], x1[2 * L])}});
+            st2_nt(d.cn_e + ((int64_t)j << d.tp_shift) + t, D2{{sum3(x0[0], x0[L], x0[2 * L]), sum3(x1[0], x1[L], x1[2 * L])}});
         }
     }
     if (KKT) {

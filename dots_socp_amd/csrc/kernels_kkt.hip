@@ -426,7 +426,7 @@ __global__ __launch_bounds__(BLOCK) void k_kkt_dual_alpha_carried(Dev d, KktArgs
         const int j0 = d.cptr[v], j1 = d.cptr[v + 1];
         const double *__restrict__ g = d.cn_e + t;
         for (int j = j0; j < j1; j += 2) {
-            const D2 g0 = ld2(g + ((int64_t)j << d.tp_shift)), g1 = ld2(g + ((int64_t)min(j + 1, j1 - 1) << d.tp_shift));
+            const D2 g0 = ld2_nt(g + ((int64_t)j << d.tp_shift)), g1 = ld2_nt(g + ((int64_t)min(j + 1, j1 - 1) << d.tp_shift));
             dsx[0] += g0.v[0];
             dsx[1] += g0.v[1];
             if (j + 1 < j1) {
