@@ -19,7 +19,7 @@ done
 # the slab formulation on one rank (rehearsal): kernels by grid
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kts -o s -- python profiles/tools/slab_profile.py torus100k 100 > gpurun_out/r04_slab.log 2>&1
 python profiles/tools/trace_by_grid.py $(find gpurun_out/kts -name s_kernel_trace.csv | head -1) > gpurun_out/r04_torus100k_slab_by_grid.txt
-tail -1 gpurun_out/r04_slab.log > gpurun_out/r04_torus100k_slab_ms.txt
+grep "slab iteration" gpurun_out/r04_slab.log > gpurun_out/r04_torus100k_slab_ms.txt
 rm -rf gpurun_out/kts
 python bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.log
 python bench.py --steps 20 --warmup 5 > gpurun_out/r04_bench_driver_style.json 2> gpurun_out/r04_bench_driver_style.log
