@@ -246,6 +246,9 @@ static int build(Ctx *c, const dots_problem_desc *p) {
     if (!sharded && (rc = dev_alloc(c, &d.cg_b, nnode))) return rc;      // a slab writes its right-hand side into slab.b_send
     if ((rc = dev_alloc(c, &d.lamc, nnode))) return rc;
     if (!sharded && ((rc = dev_alloc(c, &c->zf_alt, nnode)) || (rc = dev_alloc(c, &c->ze_alt, nnode)) || (rc = dev_alloc(c, &c->lamc_alt, nnode)))) return rc;
+    if (!sharded && c->zmid_defer && p->lap_solver == DOTS_LAP_MODAL_PCG && (rc = dev_alloc(c, &c->B_alt, array_count_device(d, DOTS_B)))) return rc;
+    d.B_st = d.B;
+    d.bm_st = d.bm;
     if (sharded) {
         double *hv = nullptr;
         if ((rc = dev_alloc(c, &hv, V))) return rc;
@@ -410,6 +413,10 @@ static int run_iteration_body(Ctx *c, dots_step_stats *st, hipEvent_t *tv) {
     int rc;
 #define MARK(i) do { if (tv) DOTS_HIP(hipEventRecord(tv[i], c->stream)); } while (0)
     MARK(0);
+    if (c->zmid_deferred) {      // nobody asked for the last iterate's z_mid: its storage (holding the old beta_mid) is simply stale
+        if (c->step_palm) { if ((rc = materialise_zmid(c))) return rc; }      // (step 0 reads z_mid)
+        else { c->zmid_deferred = 0; c->zmid_stale = 1; }
+    }
     // a pending penalty division rides in this iteration's kernels when both of them can apply it; otherwise it is carried out first
     const int zmode = c->step_skip_zmid ? 2 : 1;
     double dv = 0.0;
@@ -555,6 +562,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
         ok &= env_int("DOTS_KKT_TWO", 0, 1, &c->kkt_two);
         ok &= env_int("DOTS_RHS_TWO", 0, 1, &c->rhs_two);
         ok &= env_int("DOTS_RHS_TILES", 0, 2, &c->rhs_tiles);
+        ok &= env_int("DOTS_ZMID_DEFER", 0, 1, &c->zmid_defer);    // 0: read-back iterations store z_mid as before
         ok &= env_int("DOTS_LAZY_DIV", 0, 1, &c->lazy_div);        // 0: a penalty update divides the dual arrays at once
         ok &= env_int("DOTS_CARRY", 0, 1, &c->carry_arrays);       // 0: never allocate the carried gathers (DOTS_STEP_CARRY is then ignored)
         ok &= env_int("DOTS_SPIN_FETCH", 0, 1, &c->spin_fetch);
@@ -629,10 +637,11 @@ int dots_upload(dots_ctx *c, int id, const double *host, int64_t count) {
     int rc = check(c);
     if (rc) return rc;
     if (id < 0 || id >= DOTS_N_ARRAYS || !host || count != array_count_host(c->d, id)) { set_error("upload: bad array id or element count"); return DOTS_ERR_ARGUMENT; }
+    if (id != DOTS_Z_MID && (rc = materialise_zmid(c))) return rc;
     DOTS_HIP(hipMemcpyAsync(c->stage, host, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
     if ((rc = launch_to_device_layout(c, id, c->stage))) return rc;
     DOTS_HIP(hipStreamSynchronize(c->stream));
-    if (id == DOTS_Z_MID) c->zmid_stale = 0;
+    if (id == DOTS_Z_MID) { c->zmid_stale = 0; c->zmid_deferred = 0; }      // (the upload is what z_mid's storage now holds)
     c->kkt_halo_fresh = 0;
     return 0;
 }
@@ -641,6 +650,7 @@ int dots_download(dots_ctx *c, int id, double *host, int64_t count) {
     if (rc) return rc;
     if (id < 0 || id >= DOTS_N_ARRAYS || !host || count != array_count_host(c->d, id)) { set_error("download: bad array id or element count"); return DOTS_ERR_ARGUMENT; }
     if (id == DOTS_Z_MID && c->zmid_stale) { set_error("download: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
+    if (id == DOTS_Z_MID && (rc = materialise_zmid(c))) return rc;
     if ((rc = launch_from_device_layout(c, id, c->stage))) return rc;
     DOTS_HIP(hipMemcpyAsync(host, c->stage, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     DOTS_HIP(hipStreamSynchronize(c->stream));
@@ -842,6 +852,7 @@ int dots_run_phase(dots_ctx *c, int phase, dots_step_stats *stats) {
     if (c->shard_stride != 0) { set_error("run_phase works on whole arrays: not available on a time slab"); return DOTS_ERR_STATE; }
     dots_step_stats local;
     memset(&local, 0, sizeof local);
+    if ((rc = materialise_zmid(c))) return rc;
     switch (phase) {
         case DOTS_PHASE_LAPLACIAN:
             if ((rc = launch_rhs(c))) return rc;
@@ -868,6 +879,7 @@ int dots_kkt(dots_ctx *c, uint32_t mask, double *out) {
     if (!mask) return 0;
     if (c->zmid_stale && (mask & (1u << DOTS_KKT_PRIM_Z))) { set_error("kkt: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
     if (c->shard_stride != 0) { set_error("kkt on a time slab: use dots_kkt_sums / dots_kkt_combine around the caller's all-reduce"); return DOTS_ERR_STATE; }
+    if ((mask & (1u << DOTS_KKT_PRIM_Z)) && !kkt_takes_fused(c, mask) && (rc = materialise_zmid(c))) return rc;      // (the stand-alone kernels read z_mid)
     return kkt_evaluate(c, mask, out);
 }
 int dots_kkt_sums(dots_ctx *c, uint32_t mask, double *sums) {
@@ -882,6 +894,7 @@ int dots_kkt_sums(dots_ctx *c, uint32_t mask, double *sums) {
         set_error("kkt_sums: the KKT halos are stale (dots_slab_stage 4 + exchange first)");
         return DOTS_ERR_STATE;
     }
+    if ((mask & (1u << DOTS_KKT_PRIM_Z)) && !kkt_takes_fused(c, mask) && (rc = materialise_zmid(c))) return rc;
     return kkt_sums(c, mask, sums);
 }
 int dots_kkt_sums_device(dots_ctx *c, uint32_t mask, double *device_sums) {
@@ -939,6 +952,7 @@ int dots_scale_z(dots_ctx *c, double z_mul, double beta_mul, double sz_new) {
     int rc = check(c);
     if (rc) return rc;
     c->kkt_halo_fresh = 0;
+    if ((rc = materialise_zmid(c))) return rc;
     return launch_scale_z(c, z_mul, beta_mul, sz_new);
 }
 int dots_scale_arrays(dots_ctx *c, uint32_t mask, double factor) {
@@ -946,6 +960,7 @@ int dots_scale_arrays(dots_ctx *c, uint32_t mask, double factor) {
     if (rc) return rc;
     if (mask >> DOTS_N_ARRAYS) { set_error("bad array mask"); return DOTS_ERR_ARGUMENT; }
     c->kkt_halo_fresh = 0;
+    if ((rc = materialise_zmid(c))) return rc;
     for (int id = 0; id < DOTS_N_ARRAYS; ++id)
         if ((mask >> id) & 1u)
             if ((rc = launch_scale_array(c, id, factor))) return rc;
@@ -956,6 +971,7 @@ int dots_norm_square(dots_ctx *c, int id, int part, double *out) {
     if (rc) return rc;
     if (id < 0 || id >= DOTS_N_ARRAYS || !out || part < 0 || part > 2) { set_error("norm_square: bad argument"); return DOTS_ERR_ARGUMENT; }
     if (id == DOTS_Z_MID && c->zmid_stale) { set_error("norm_square: z_mid was not materialised by the last step (dots_step_flags)"); return DOTS_ERR_STATE; }
+    if (id == DOTS_Z_MID && (rc = materialise_zmid(c))) return rc;
     return norm_square(c, id, part, out);
 }
 

@@ -76,6 +76,8 @@ struct Dev {
     const double *sigma;     // [T+1] or null
     // state
     double *phi, *A, *B, *lam, *zf, *zm, *ze, *mu, *E, *bf, *bm, *be;
+    double *B_st, *bm_st;    // where steps 2+3 (k_q_lambda_mult_carry) STORE the new B and beta_mid: the arrays themselves, or -- on an iteration
+                             // whose z_mid may be asked for -- the alternate B buffer and z_mid's storage (Ctx::zmid_deferred)
     double *lamc;            // [V][TP] cone multiplier of the last projection (z_mid = lamc/D * pre-image, rebuilt in steps 2+3)
     // DOTS_STEP_CARRY (one GPU, direct solver, pitch <= 128; null otherwise): what the right-hand side and the cone projection of the
     // NEXT iteration gather per corner, stored by steps 2+3 in corner-LIST order (row j = position in cidx; cpos: f*3+k -> j)
@@ -238,6 +240,7 @@ int launch_rhs(Ctx *c, bool with_soc = false, double dv = 0.0);   // with_soc (o
 bool rhs_divides(const Ctx *c);
 bool ql_divides(const Ctx *c, int zmid_mode);
 int launch_q_lambda_mult(Ctx *c, int zmid_mode = 0, double dv = 0.0);    // 0: read z_mid; 1: rebuild it from the multiplier and store it; 2: rebuild, do not store; dv != 0 (only when ql_divides): the dual arrays are divided as they are read and written back divided
+int materialise_zmid(Ctx *c);                            // z_mid rebuilt from the old B / beta_mid a deferred step kept (no-op otherwise)
 int launch_q_lambda_only(Ctx *c);                       // the (q, lambda_c) closed form alone (is_palm's step 0): z_mid is read from memory
 int launch_adjust_penalty(Ctx *c, double factor);
 int launch_scale_z(Ctx *c, double z_mul, double beta_mul, double sz_new);
@@ -342,6 +345,14 @@ struct Ctx {
     int step_carry = 0;           // dots_step_flags: steps 2+3 also store the next iteration's per-corner gathers (cn_sq, cn_g)
     int carry_valid = 0;          // ... and they belong to the current iterate (cleared by every call that changes state or parameters)
     int zmid_stale = 0;           // z_mid does not belong to the current iterate
+    // z_mid on demand (one GPU, carry mapping): an iteration after which z_mid MAY be read (residuals read back, possibly the last one) does
+    // not store it (18 T F values that are almost never read); instead steps 2+3 write the new beta_mid into z_mid's storage and the new B
+    // into an alternate buffer and the pointers are swapped, so that the old B and beta_mid -- the pre-image of the projection, from which
+    // z_mid = (lambda / D) * D (s_z/sqrt3 B_old - beta_mid_old) is rebuilt bit for bit (k_rebuild_zmid) -- survive until the next iteration.
+    double *B_alt = nullptr;      // [3F][TP]
+    int zmid_deferred = 0;        // z_mid's storage holds the OLD beta_mid, B_alt the OLD B: materialise_zmid() before anything reads z_mid
+    double zmid_dv = 0.0, zmid_sz = 0.0;   // the penalty division that was pending during that step (0: none); scale_factor_z of that step
+    int zmid_defer = 1;           // DOTS_ZMID_DEFER=0: store z_mid on those iterations as before (A/B measurements)
     FrontDev front{};             // multifrontal factor (n_nodes == 0: none)
     int use_front = 0;
     int front_fwd_ptr[66]{}, front_bwd_ptr[66]{};   // workgroup ranges of the tree levels in fwd_desc / bwd_desc
@@ -421,6 +432,11 @@ inline bool carry_possible(const Ctx *c) {
 }
 // ... or the projection itself rides in the right-hand-side launch (enqueue-only iterations; TILE_ELEMS threads per tile)
 inline bool rhs_takes_soc(const Ctx *c) { return c->soc_with_rhs && rhs_writes_modes(c); }
+
+// a KKT evaluation of the conditions in `mask` reduces the sums the last steps-2+3 launch left (kernels_kkt.hip: kkt_sums) and reads no z_mid
+inline bool kkt_takes_fused(const Ctx *c, uint32_t mask) {
+    return c->kkt_fused_valid && !(mask & ~(KKT_FUSED_MASK | 4u)) && c->spin_fetch && c->h_mail && c->kkt_counter;
+}
 
 int64_t array_count_host(const Dev &d, int array_id);    // elements in the reference layout
 int64_t array_count_device(const Dev &d, int array_id);  // elements in the device layout

@@ -986,13 +986,13 @@ __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, doub
                 st2_nt(d.zm + idxM(d, f * 3 + k, 1, c, t - 1), z1[k]);
             }
         }
-        st2(d.B + ie, Bn);
+        st2(d.B_st + ie, Bn);
         if (QONLY) return;
         st2(d.E + ie, En);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            st2(d.bm + idxM(d, f * 3 + k, 0, c, t), n0[k]);
-            st2(d.bm + idxM(d, f * 3 + k, 1, c, t - 1), n1[k]);
+            st2(d.bm_st + idxM(d, f * 3 + k, 0, c, t), n0[k]);
+            st2(d.bm_st + idxM(d, f * 3 + k, 1, c, t - 1), n1[k]);
         }
     } else {      // only the first node of the pair exists: element-wise stores
         const bool has0 = t < d.ni, has1 = has1_0;
@@ -1003,13 +1003,13 @@ __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, doub
                 if (has1) d.zm[idxM(d, f * 3 + k, 1, c, t - 1)] = z1[k].v[0];
             }
         }
-        d.B[ie] = Bn.v[0];
+        d.B_st[ie] = Bn.v[0];
         if (QONLY) return;
         d.E[ie] = En.v[0];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            if (has0) d.bm[idxM(d, f * 3 + k, 0, c, t)] = n0[k].v[0];
-            if (has1) d.bm[idxM(d, f * 3 + k, 1, c, t - 1)] = n1[k].v[0];
+            if (has0) d.bm_st[idxM(d, f * 3 + k, 0, c, t)] = n0[k].v[0];
+            if (has1) d.bm_st[idxM(d, f * 3 + k, 1, c, t - 1)] = n1[k].v[0];
         }
     }
 }
@@ -1219,6 +1219,43 @@ __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carr
     }
 }
 
+// z_mid on demand (Ctx::zmid_deferred): in place on z_mid's storage, which holds the beta_mid the last projection read;
+// Bold: the B it read.  One node per lane; the expression of the steps-2+3 kernels (ZMODE 1), entry for entry.
+__global__ __launch_bounds__(BLOCK) void k_rebuild_zmid(Dev d, const double *__restrict__ Bold, double sz, double dv) {
+    const int tile = xcd_tile(blockIdx.x, d.n_ftiles);
+    if (tile >= d.n_ftiles) return;
+    const double sB = sz * INV_SQRT3;
+    for (int e = threadIdx.x; e < TILE_ELEMS; e += BLOCK) {
+        const int row = tile * d.FT + (e >> d.tp_shift), t = e & (d.TP - 1);
+        if (row >= 3 * d.F || t >= d.nl) continue;
+        const int f = row / 3, c = row - 3 * f;
+        const bool has0 = t < d.ni, has1 = has_prev_interval(d, t);
+        const double sBold = sB * Bold[idxF(d, f, c, t)];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int vk = d.tri[f * 3 + k];
+            const double Dk = d.fk_D[f * 3 + k];
+            if (has0) {
+                double b = d.zm[idxM(d, f * 3 + k, 0, c, t)];
+                if (dv != 0.0) b /= dv;
+                d.zm[idxM(d, f * 3 + k, 0, c, t)] = (d.lamc[idxV(d, vk, t)] / Dk) * (Dk * (sBold - b));
+            }
+            if (has1) {
+                double b = d.zm[idxM(d, f * 3 + k, 1, c, t - 1)];
+                if (dv != 0.0) b /= dv;
+                d.zm[idxM(d, f * 3 + k, 1, c, t - 1)] = (d.lamc[idxV(d, vk, t - 1)] / Dk) * (Dk * (sBold - b));
+            }
+        }
+    }
+}
+int materialise_zmid(Ctx *c) {
+    if (!c->zmid_deferred) return 0;
+    c->zmid_deferred = 0;
+    hipLaunchKernelGGL(k_rebuild_zmid, dim3(xcd_grid(c->d.n_ftiles)), dim3(BLOCK), 0, c->stream, c->d, c->B_alt, c->zmid_sz, c->zmid_dv);
+    DOTS_HIP(hipGetLastError());
+    return 0;
+}
+
 // Step 0 of is_palm = True: (A, B, lambda_c) from the current multipliers and the stored z_mid; nothing else moves.
 int launch_q_lambda_only(Ctx *c) {
     const dots_params &p = c->prm;
@@ -1253,16 +1290,33 @@ int launch_q_lambda_mult(Ctx *c, int zmid_mode, double dv) {
         kf.nf = n_fwg;
         const bool k = kkt && nv8 <= c->kkt_fused_cap_v && n_fwg <= c->kkt_fused_cap_f;
         const int emit = (carry ? 1 : 0) | (k ? 2 : 0);
+        // z_mid on demand: nothing of it is stored; the new B / beta_mid go to the alternate buffers, the old ones stay (Ctx::zmid_deferred)
+        const bool defer = zmid_mode == 1 && c->zmid_defer && c->B_alt && !c->d.slab && !c->step_palm;
+        Dev dk = c->d;
+        if (defer) { dk.B_st = c->B_alt; dk.bm_st = c->d.zm; }
 #define CARRY_LAUNCH(Z, K)                                                                                                                                     \
     do {                                                                                                                                                     \
-        if (dv != 0.0) hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, true>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, dv, emit); \
-        else hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, false>), g, dim3(CARRY_NB), 0, c->stream, c->d, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, 1.0, emit);        \
+        if (dv != 0.0) hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, true>), g, dim3(CARRY_NB), 0, c->stream, dk, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, dv, emit); \
+        else hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, false>), g, dim3(CARRY_NB), 0, c->stream, dk, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, 1.0, emit);        \
     } while (0)
         if (zmid_mode == 2) CARRY_LAUNCH(2, false);
+        else if (defer && k) CARRY_LAUNCH(2, true);
+        else if (defer) CARRY_LAUNCH(2, false);
         else if (k) CARRY_LAUNCH(1, true);
         else CARRY_LAUNCH(1, false);
 #undef CARRY_LAUNCH
         DOTS_HIP(hipGetLastError());
+        if (defer) {
+            std::swap(c->d.B, c->B_alt);          // B_alt: the B the projection read
+            std::swap(c->d.bm, c->d.zm);          // z_mid's storage: the beta_mid it read
+            c->d.B_st = c->d.B;
+            c->d.bm_st = c->d.bm;
+            c->dcg.B = c->dgt.B = c->d.B; c->dcg.bm = c->dgt.bm = c->d.bm; c->dcg.zm = c->dgt.zm = c->d.zm;
+            c->dcg.B_st = c->dgt.B_st = c->d.B; c->dcg.bm_st = c->dgt.bm_st = c->d.bm;
+            c->zmid_deferred = 1;
+            c->zmid_dv = dv;
+            c->zmid_sz = p.scale_z;
+        }
         c->carry_valid = carry ? 1 : 0;
         if (k) { c->kkt_fused = kf; c->kkt_fused_valid = 1; }
         return 0;
@@ -1544,6 +1598,7 @@ void preload_alm_kernels() {
         (const void *)k_q_lambda_mult_triangle2<0>, (const void *)k_q_lambda_mult_triangle2<1>, (const void *)k_q_lambda_mult_triangle2<2>,
         (const void *)k_q_lambda_mult_carry<1>, (const void *)k_q_lambda_mult_carry<2>, (const void *)k_q_lambda_mult_carry<1, true>,
         (const void *)k_q_lambda_mult_carry<1, false, true>, (const void *)k_q_lambda_mult_carry<2, false, true>, (const void *)k_q_lambda_mult_carry<1, true, true>,
+        (const void *)k_q_lambda_mult_carry<2, true, false>, (const void *)k_q_lambda_mult_carry<2, true, true>, (const void *)k_rebuild_zmid,
 
         (const void *)k_divide_five, (const void *)k_scale, (const void *)k_divide, (const void *)k_rebuild_mu, (const void *)k_rebuild_E,
     };

@@ -620,7 +620,7 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
     // DOTS_STEP_KKT_SUMS: the last steps-2+3 launch left the sums of Prim(phi, q), Prim(q, z), Dual(beta) and Comp(rho, cong.)
     // (no pass over the state for them); Dual(alpha) gathers E over the corner lists: the vertex kernel alone, with that
     // condition only.  Conditions that gather more (4, 5) take the kernels of this file for everything.
-    const bool fused = c->kkt_fused_valid && !(mask & ~(KKT_FUSED_MASK | 4u)) && c->spin_fetch && c->h_mail && c->kkt_counter;
+    const bool fused = kkt_takes_fused(c, mask);
     ReduceSrc src = reduce_src(d.partials, nv, part_f, nf);
     bool have[N_SUMS];
     for (int i = 0; i < N_SUMS; ++i) have[i] = (i < N_VSUMS) ? need_v : need_f;

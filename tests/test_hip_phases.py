@@ -482,6 +482,68 @@ def test_penalty_division_left_to_the_next_iteration(fixture, T, monkeypatch):
     assert a[1] == b[1] and a[2] == b[2]
 
 
+@pytest.mark.parametrize("fixture,T", [("ops_ico1.npz", None), ("ops_torus8x6.npz", 30), ("ops_refplane4.npz", 63)])
+def test_z_mid_on_demand_equals_the_stored_one(fixture, T, monkeypatch):
+    """Iterations after which z_mid may be read do not store it: steps 2+3 write the new B / beta_mid into alternate buffers and z_mid is
+    rebuilt from the OLD ones when something asks for it (download, Prim(q, z) through the stand-alone kernels, norms, a rescaling,
+    is_palm's step 0, a single phase) -- with a penalty division pending during the step too.  DOTS_ZMID_DEFER=0 stores it as before:
+    the same numbers bit for bit, whatever is asked for and in whatever order."""
+    from dots_socp_amd.device import DeviceProblem
+
+    g = golden(fixture)
+    geom = dict(vertices=g["vertices"], triangles=g["triangles"], mu0=g["mu0"], mu1=g["mu1"])
+    T = int(g["n_time"]) if T is None else T
+
+    def run(defer):
+        monkeypatch.setenv("DOTS_ZMID_DEFER", defer)
+        dev = DeviceProblem(T, geom, lap_solver="modal_pcg")
+        dev.setup_frontal(leaf=4)
+        dev.scale_z(2.0, 0.5, 2.0)
+        dev.set_params(scale_z=2.0, const_d=2.0, congestion=0.05)
+        res, r = [], 1.0
+        for k in range(14):
+            reads = k % 2 == 1
+            dev.step_flags(skip_z_mid=not reads and k != 12, carry=True, kkt_sums=reads and k != 9, palm=k == 12)
+            dev.step(1, wait=False)
+            if k == 1:
+                res.append(dev.download("z_mid").copy())                 # rebuilt for the download
+                res.append(dev.kkt([1]))                                   # (already materialised)
+            if k == 3:
+                res.append(dev.kkt([0, 1, 2, 3]))                          # the sums steps 2+3 left: z_mid is not touched
+                res.append(dev.kkt(range(7)))                              # conditions 4, 5: the stand-alone kernels read z_mid
+                r *= 1.6
+                dev.adjust_penalty(1.6)
+                dev.set_params(r=r)
+            if k == 5:                                                     # the step applied the pending division itself
+                res.append(dev.norm_square("z_mid"))
+                res.append(dev.download("beta_mid").copy())
+            if k == 7:
+                dev.scale_z(3.0, 1.0 / 3.0, 3.0)                           # scales z_mid: rebuilt first
+                dev.set_params(scale_z=3.0, const_d=3.0)
+                res.append(dev.download("z_mid").copy())
+            if k == 9:
+                res.append(dev.kkt([1, 3]))                                # no fused sums on this step: the stand-alone kernels
+            if k == 11:
+                pass                                                       # nobody asks: the next step (is_palm: step 0 reads z_mid) must rebuild it
+            if k == 13:
+                res.append(dev.download("B").copy())
+        dev.step_flags(skip_z_mid=False)
+        dev.step(1)
+        out = (dev.download_all(), dev.kkt(range(7)), res)
+        dev.close()
+        return out
+
+    a, b = run("0"), run("1")
+    for k in a[0]:
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert a[1] == b[1]
+    for x, y in zip(a[2], b[2]):
+        if isinstance(x, np.ndarray):
+            assert np.array_equal(x, y)
+        else:
+            assert x == y
+
+
 def test_carry_flag_is_a_hint():
     """DOTS_STEP_CARRY is ignored without the direct solver and with is_palm's step 0 (which moves B before the right-hand side)."""
     from dots_socp_amd.device import DeviceProblem
