@@ -29,9 +29,14 @@ EXPORTS = [
     "dots_objective", "dots_adjust_penalty", "dots_scale_z", "dots_scale_arrays", "dots_norm_square",
     "dots_apply_operator", "dots_bench_kernel", "dots_device_bytes", "dots_mg_setup", "dots_mg_enable",
     "dots_slab_elems", "dots_slab_set_buffers", "dots_slab_stage", "dots_kkt_sums", "dots_kkt_sums_device", "dots_debug_counter", "dots_kkt_combine", "dots_objective_sums",
-    "dots_objective_combine", "dots_front_launches", "dots_front_info", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_step_flags", "dots_step_times", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
+    "dots_objective_combine", "dots_front_launches", "dots_front_info", "dots_front_setup", "dots_front_enable", "dots_front_pitch", "dots_penalty_ahead", "dots_step_flags", "dots_step_times", "dots_stream_wait", "dots_tree_build", "dots_tree_nodes", "dots_tree_copy", "dots_tree_free",
     "dots_patch_order", "dots_assemble", "dots_assemble_nnz", "dots_assemble_copy", "dots_assemble_free", "dots_symbolic_build", "dots_symbolic_front_rows", "dots_symbolic_copy", "dots_symbolic_free",
 ]
+
+
+class PenaltyPolicy(C.Structure):      # dots_penalty_policy
+    _fields_ = [("tol", C.c_double), ("r_lower", C.c_double), ("r_upper", C.c_double), ("is_org_kkt", C.c_int32), ("n_steps", C.c_int32),
+                ("threshold", C.c_double * 16), ("factor", C.c_double * 16)]
 
 
 class HipLibraryError(RuntimeError):
@@ -254,6 +259,7 @@ def load(host_only=False):
     lib.dots_front_launches.argtypes = [vp]
     lib.dots_front_info.argtypes = [vp, _f64p]
     lib.dots_step_flags.argtypes = [vp, C.c_uint32]
+    lib.dots_penalty_ahead.argtypes = [vp, C.POINTER(PenaltyPolicy)]
     lib.dots_step_times.argtypes = [vp, C.POINTER(StepStats), C.c_int, C.c_int, C.POINTER(C.c_int)]
     lib.dots_stream_wait.argtypes = [vp, vp, C.c_int]
     i64p = C.POINTER(C.c_int64)

@@ -339,7 +339,7 @@ static int check(dots_ctx *ctx, bool reads_only = false, bool keeps_division = f
     if (!ctx) { set_error("null context"); return DOTS_ERR_ARGUMENT; }
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
-    if (!reads_only) ctx->rhs_ahead = ctx->rhs_ahead_armed = ctx->carry_valid = ctx->kkt_fused_valid = 0;      // (the carried gathers / fused sums belong to the state steps 2+3 left)
+    if (!reads_only) ctx->rhs_ahead = ctx->rhs_ahead_armed = ctx->penalty_armed = ctx->carry_valid = ctx->kkt_fused_valid = 0;      // (the carried gathers / fused sums belong to the state steps 2+3 left)
     if (!keeps_division) return flush_division(ctx);
     return 0;
 }
@@ -421,15 +421,19 @@ static int run_iteration_body(Ctx *c, dots_step_stats *st, hipEvent_t *tv) {
     const int zmode = c->step_skip_zmid ? 2 : 1;
     double dv = 0.0;
     if (c->pending_div != 0.0) {
-        if (!st && !c->step_palm && !c->rhs_ahead && rhs_takes_soc(c) && rhs_divides(c) && ql_divides(c, zmode)) {
+        if (!st && !c->step_palm && c->rhs_ahead == 2 && c->ahead_div == c->pending_div && ql_divides(c, zmode)) {
+            dv = c->pending_div;      // the launch ahead (penalty_decision_ahead) divided as it read: steps 2+3 do the same and write back divided
+            c->pending_div = 0.0;
+        } else if (!st && !c->step_palm && !c->rhs_ahead && rhs_takes_soc(c) && rhs_divides(c) && ql_divides(c, zmode)) {
             dv = c->pending_div;
             c->pending_div = 0.0;
-        } else if ((rc = flush_division(c))) return rc;
+        } else if ((rc = flush_division(c))) return rc;      // (a launch ahead that divided as it read saw the values the arrays now hold)
     }
+    c->ahead_div = 0.0;
     if ((rc = palm_step0(c))) return rc;
     // the right-hand side of this iteration was enqueued behind the KKT kernels of the last one (DOTS_STEP_RHS_AHEAD) and nothing
     // it reads has changed since: start at the solve; the projection then runs with the inverse transform
-    const int ahead_kind = c->step_palm ? 0 : c->rhs_ahead;
+    const int ahead_kind = (c->step_palm || c->rhs_ahead > 2) ? 0 : c->rhs_ahead;      // (3, 4: an anticipated penalty update the caller did not confirm)
     const bool ahead = ahead_kind != 0;
     c->rhs_ahead = 0;
     if (ahead_kind == 2) {      // the projection ran ahead too: its results become the current z_fst, z_end and cone multiplier
@@ -461,7 +465,7 @@ static int run_iteration_body(Ctx *c, dots_step_stats *st, hipEvent_t *tv) {
         MARK(2);
         if (ahead_kind != 2 && (rc = launch_soc_projection(c, 1, fuse))) return rc;
         MARK(3);
-        if ((rc = launch_q_lambda_mult(c, c->step_skip_zmid ? 2 : 1))) return rc;
+        if ((rc = launch_q_lambda_mult(c, zmode, dv))) return rc;
         MARK(4);
         MARK(5);
         return 0;
@@ -609,10 +613,30 @@ int dots_destroy(dots_ctx *c) {
 }
 
 int dots_set_params(dots_ctx *c, const dots_params *p) {
+    // the penalty update the library anticipated (penalty_decision_ahead): only r moves, to the anticipated value
+    const bool anticipated = c && p && c->rhs_ahead == 4 && p->r == c->ahead_r && p->scale_z == c->prm.scale_z && p->const_d == c->prm.const_d &&
+                             p->eps == c->prm.eps && p->boundary_scale == c->prm.boundary_scale && p->congestion == c->prm.congestion && p->tau == c->prm.tau;
     int rc = check(c, false, true);
     if (rc) return rc;
     if (!p || !(p->r > 0) || !(p->scale_z > 0) || !(p->cg_tol > 0) || p->eps < 0 || !(p->boundary_scale > 0)) { set_error("bad parameters"); return DOTS_ERR_ARGUMENT; }
     c->prm = *p;
+    if (anticipated && c->pending_div == c->ahead_dv) {
+        c->rhs_ahead = 2;
+        c->ahead_div = c->ahead_dv;
+        c->penalty_ahead_confirmed += 1;
+    }
+    return 0;
+}
+
+int dots_penalty_ahead(dots_ctx *c, const dots_penalty_policy *policy) {
+    int rc = check(c, true, true);
+    if (rc) return rc;
+    if (!policy || policy->n_steps < 0 || policy->n_steps > 16 || !(policy->tol > 0) || !(policy->r_lower > 0) || !(policy->r_upper >= policy->r_lower)) {
+        set_error("penalty_ahead: bad policy");
+        return DOTS_ERR_ARGUMENT;
+    }
+    c->penalty_policy = *policy;
+    c->penalty_armed = 1;
     return 0;
 }
 int dots_get_params(dots_ctx *c, dots_params *p) {
@@ -936,6 +960,7 @@ int dots_objective(dots_ctx *c, double *out) {
 }
 
 int dots_adjust_penalty(dots_ctx *c, double factor) {
+    const bool anticipated = c && c->rhs_ahead == 3 && factor == c->ahead_dv;      // (penalty_decision_ahead; check() drops the launch ahead)
     int rc = check(c);      // (carries out a division that is still pending)
     if (rc) return rc;
     if (!(factor > 0)) { set_error("factor must be positive"); return DOTS_ERR_ARGUMENT; }
@@ -944,6 +969,7 @@ int dots_adjust_penalty(dots_ctx *c, double factor) {
     // the arrays carries it out first (check)
     if (c->lazy_div && c->shard_stride == 0 && carry_possible(c)) {
         c->pending_div = factor;
+        if (anticipated) c->rhs_ahead = 4;      // ... kept if dots_set_params now brings the anticipated penalty
         return 0;
     }
     return launch_adjust_penalty(c, factor);
@@ -1161,6 +1187,8 @@ int64_t dots_debug_counter(dots_ctx *c, int which) {
     switch (which) {
         case 0: return c->mail_fallbacks;
         case 1: return (int64_t)c->mail_seq;
+        case 2: return c->penalty_ahead_started;
+        case 3: return c->penalty_ahead_confirmed;
         default: return -1;
     }
 }

@@ -265,6 +265,7 @@ int kkt_evaluate(Ctx *c, uint32_t mask, double *out);
 int kkt_sums(Ctx *c, uint32_t mask, double *sums);                          // the weighted sums of this context's time slab
 int kkt_sums_device(Ctx *c, uint32_t mask, double *device_sums);            // the same, left in the caller's device buffer (enqueue only)
 int kkt_combine(Ctx *c, uint32_t mask, const double *sums, double *out);    // the residuals from the sums of the whole problem
+int penalty_decision_ahead(Ctx *c, uint32_t mask, const double *sums);       // dots_penalty_ahead: the decision + the next iteration's first launch
 bool env_int(const char *name, int lo, int hi, int *out);                   // validated integer switch from the environment
 int kkt_n_sums();
 int objective_evaluate(Ctx *c, double *out);
@@ -365,6 +366,13 @@ struct Ctx {
     int rhs_ahead_armed = 0;      // DOTS_STEP_RHS_AHEAD: the next KKT launch is followed by the next iteration's right-hand side
     int rhs_ahead = 0;            // ... which is on the stream and still valid (any call that changes state or parameters clears it); 2: with the
                                   // cone projection, whose results (z_fst, z_end, the cone multiplier) wait in the alternate buffers below
+                                  // 3 / 4: started by the penalty decision ahead of the host (dots_penalty_ahead) with the division `ahead_dv` applied as it read and
+                                  // the penalty `ahead_r`; becomes 2 when dots_adjust_penalty (3 -> 4) and dots_set_params (4 -> 2) confirm both
+    int penalty_armed = 0;        // dots_penalty_ahead: the next evaluation of conditions 0-3 takes the penalty decision itself
+    dots_penalty_policy penalty_policy{};
+    double ahead_dv = 0.0, ahead_r = 0.0;   // what the launch ahead anticipated
+    int64_t penalty_ahead_started = 0, penalty_ahead_confirmed = 0;   // diagnostics (dots_debug_counter 2, 3)
+    double ahead_div = 0.0;       // rhs_ahead == 2: the division the launch ahead applied as it read (steps 2+3 of the step that takes it must apply the same)
     double *zf_alt = nullptr, *ze_alt = nullptr, *lamc_alt = nullptr;   // [V][TP] each (one GPU): written ahead, swapped in by the step that takes them
     int front_rb_max = 4;         // most rows (columns) of a node per workgroup (DOTS_FRONT_RB: 1, 2 or 4, for A/B measurements)
     double front_bytes = 0.0;     // factor bytes one solve reads (both sweeps, merged blocks as stored)

@@ -682,6 +682,62 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
     if (rc) return rc;
     // slots of kernels that did not run hold leftovers of earlier calls: report zeros there
     for (int i = 0; i < N_SUMS; ++i) sums[i] = have[i] ? c->h_pinned[i] : 0.0;
+    if (c->penalty_armed) {
+        c->penalty_armed = 0;
+        if ((rc = penalty_decision_ahead(c, mask, sums))) return rc;
+    }
+    return 0;
+}
+
+// dots_penalty_ahead: the reference's penalty decision (solver_socp.py:806-823, admm_tools.py:54-95) taken here, from the sums that have just
+// arrived, so that the next iteration's first launch is on the stream before the host has even returned to its own (identical) decision.
+int penalty_decision_ahead(Ctx *c, uint32_t mask, const double *sums) {
+    const dots_penalty_policy &pp = c->penalty_policy;
+    if ((mask & 15u) != 15u || c->d.slab || c->step_palm || !c->lazy_div || !c->zf_alt || c->rhs_ahead || c->carry_valid || !rhs_takes_soc(c) ||
+        !rhs_divides(c) || c->pending_div != 0.0)
+        return 0;
+    double o[2 * DOTS_N_KKT];
+    int rc = kkt_combine(c, 15u, sums, o);
+    if (rc) return rc;
+    bool fails = false, finite = true;
+    double max_unit = o[1];
+    for (int i = 0; i < 4; ++i) {
+        finite = finite && std::isfinite(o[2 * i]) && std::isfinite(o[2 * i + 1]);
+        fails = fails || !(o[2 * i] < pp.tol);
+        max_unit = o[2 * i + 1] > max_unit ? o[2 * i + 1] : max_unit;
+    }
+    if (!finite || !fails) return 0;      // all four pass: the host goes on validating (and may stop); nothing is anticipated
+    const bool org = pp.is_org_kkt || max_unit < 5.0 * pp.tol;
+    const int k = org ? 0 : 1;
+    const double prim = o[k] > o[2 + k] ? o[k] : o[2 + k], dual = o[4 + k] > o[6 + k] ? o[4 + k] : o[6 + k];
+    if (!(dual > 0.0) || !(prim >= 0.0)) return 0;
+    const double gap = prim / dual;
+    const bool prim_win = gap < 1.0;
+    const double g = prim_win ? 1.0 / gap : gap;
+    double factor = 1.0;
+    for (int i = 0; i < pp.n_steps; ++i)
+        if (g > pp.threshold[i]) { factor = pp.factor[i]; break; }
+    if (prim_win) factor = 1.0 / factor;
+    const double r = c->prm.r;
+    double r_new = r * factor;
+    r_new = r_new < pp.r_upper ? r_new : pp.r_upper;
+    r_new = r_new > pp.r_lower ? r_new : pp.r_lower;
+    const double dv = r_new / r;          // what the driver hands to dots_adjust_penalty ...
+    const double r_next = r * dv;         // ... and the penalty it then sets (solver_socp.py: r *= factor)
+    if (!(dv > 0.0) || !std::isfinite(dv)) return 0;
+    Dev keep = c->d;
+    c->d.zf = c->zf_alt;
+    c->d.ze = c->ze_alt;
+    c->d.lamc = c->lamc_alt;
+    c->prm.r = r_next;
+    rc = launch_rhs(c, true, dv);
+    c->prm.r = r;
+    c->d = keep;
+    if (rc) return rc;
+    c->rhs_ahead = 3;
+    c->penalty_ahead_started += 1;
+    c->ahead_dv = dv;
+    c->ahead_r = r_next;
     return 0;
 }
 

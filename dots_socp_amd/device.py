@@ -181,6 +181,18 @@ class DeviceProblem:
                  | (_lib.STEP_TIMED if timed else 0) | (_lib.STEP_CARRY if carry else 0) | (_lib.STEP_KKT_SUMS if kkt_sums else 0))
         _lib.check(self.lib.dots_step_flags(self._h, flags), "dots_step_flags")
 
+    def penalty_ahead(self, tol, is_org_kkt, r_lower, r_upper, table):
+        """dots_penalty_ahead: the next evaluation of conditions 0-3 takes the reference's penalty decision inside the library and starts
+        the next iteration's first launch with it (``table``: (threshold, factor) pairs of admm_tools.py:79-90); a hint."""
+        pol = getattr(self, "_penalty_policy", None)
+        if pol is None:
+            pol = self._penalty_policy = _lib.PenaltyPolicy()
+            pol.n_steps = len(table)
+            for i, (bound, val) in enumerate(table):
+                pol.threshold[i], pol.factor[i] = bound, val
+        pol.tol, pol.r_lower, pol.r_upper, pol.is_org_kkt = float(tol), float(r_lower), float(r_upper), 1 if is_org_kkt else 0
+        _lib.check(self.lib.dots_penalty_ahead(self._h, C.byref(pol)), "dots_penalty_ahead")
+
     def step_times(self, wait=False, capacity=64):
         """Phase times of the timed enqueue-only steps that have finished (``wait``: of all of them), oldest first."""
         buf = getattr(self, "_times_buf", None)

@@ -421,6 +421,11 @@ class AlmSolver:
         if not self.check_kkt_step_by_step:
             if adjust:
                 validator.reset_counter()
+                if self._rhs_ahead_ok and not is_time_used_up and it + 1 < self.nit:
+                    # the library takes the decision below itself as soon as the residuals have arrived and starts the next iteration's
+                    # first launch with it, while this side is still on its way there (dots_penalty_ahead; confirmed -- or dropped -- by the
+                    # adjust_penalty / set_params calls further down: results never depend on it)
+                    self.dev.penalty_ahead(self.tol, self.is_org_kkt, params._sigma_lower_bound, params._sigma_upper_bound, params.FACTOR_STEPS)
                 self._kkt_prefetch(required)
             passed, _info = validator.validate(required)
             org, scaled = validator.collect()

@@ -290,6 +290,26 @@ int dots_kkt_combine(dots_ctx *ctx, uint32_t mask, const double *sums, double *o
  * dots_stream_wait.  Slots of sums the mask does not need (and every slot on a rank without nodes) are zero. */
 int dots_kkt_sums_device(dots_ctx *ctx, uint32_t mask, double *device_sums /* [DOTS_KKT_N_SUMS], device memory */);
 
+/* The penalty decision ahead of the host (a hint; one GPU, direct solver).  On the iterations where the reference adapts the penalty
+ * (utils/admm_tools.py:30-52) the host reads conditions 0-3, takes the decision (solver_socp.py:806-823, admm_tools.py:54-95), divides
+ * the dual arrays and only then starts the next iteration: the device idles meanwhile.  Armed with the policy's numbers, the next
+ * dots_kkt / dots_kkt_sums whose mask holds conditions 0-3 takes the SAME decision inside the library as soon as the sums have
+ * arrived -- if one of the four conditions fails tol: is_org_kkt |= (max of the unit-scale values < 5 tol); gap = max(prim) / max(dual) of
+ * the chosen values; factor from the table (the first threshold that max(gap, 1/gap) exceeds; inverted when gap < 1); r' = clamp(r *
+ * factor) -- and starts the next iteration's right-hand side + cone projection with r * (r' / r) and the division by r' / r applied
+ * as the arrays are read (results in alternate buffers, as with DOTS_STEP_RHS_AHEAD).  The caller then calls dots_adjust_penalty and
+ * dots_set_params as it would anyway: if factor and parameters are the ones anticipated (bit for bit) the next dots_step starts at the
+ * solve, otherwise -- or after any other call that changes state -- what was started is dropped.  Results never depend on the hint. */
+typedef struct dots_penalty_policy {
+    double tol;               /* the conditions pass below tol                                            */
+    double r_lower, r_upper;  /* the penalty's clamp (admm_tools.py:25-26)                                 */
+    int32_t is_org_kkt;       /* the driver's sticky flag (solver_socp.py:806-808)                         */
+    int32_t n_steps;          /* entries of the table, <= 16                                               */
+    double threshold[16];     /* descending (admm_tools.py:79-90)                                          */
+    double factor[16];
+} dots_penalty_policy;
+int dots_penalty_ahead(dots_ctx *ctx, const dots_penalty_policy *policy);
+
 /* objective_functional (solver_socp.py:417-431) as called at :773-775/:829-831:
  * out[0] = transportation cost, out[1] = Lagrangian / objective value. */
 int dots_objective(dots_ctx *ctx, double *out /* [2] */);
@@ -468,7 +488,8 @@ int dots_front_pitch(dots_ctx *ctx);
 int dots_bench_kernel(dots_ctx *ctx, int which, int reps, double *ms_per_launch, double *bytes_per_launch);
 
 /* diagnostics: which = 0 KKT read-backs whose mailbox sequence number never arrived (the sums were then copied from the
- * device scalars instead: never stale), 1 mailbox hand-overs so far; -1 for an unknown counter */
+ * device scalars instead: never stale), 1 mailbox hand-overs so far, 2 penalty decisions taken ahead of the host (dots_penalty_ahead), 3 those the
+ * caller's own decision then confirmed; -1 for an unknown counter */
 int64_t dots_debug_counter(dots_ctx *ctx, int which);
 
 /* device memory in use by the context, bytes */

@@ -301,6 +301,35 @@ def test_factor_that_does_not_fit_falls_back_to_the_multigrid_pcg(monkeypatch, c
     assert "lap_solver_fallback" not in hist2.solver_stats and hist2.solver_stats["cg_iterations"] == 0
 
 
+@pytest.mark.parametrize("fname", ["run_ico2_T15_cong_tol1e-3.npz", "run_refplane20_T31_tol1e-3.npz"])
+def test_penalty_decision_ahead_of_the_host(fname, monkeypatch):
+    """dots_penalty_ahead: on penalty-update iterations the library takes the reference's decision (solver_socp.py:806-823,
+    admm_tools.py:54-95) itself as soon as the residuals arrive and starts the next iteration's first launch with it; the driver's
+    own decision confirms it.  Every anticipation is confirmed (the two decisions are the same arithmetic), and the run is the
+    run without any launch ahead, bit for bit."""
+    from dots_socp_amd.socp.solver_socp import AlmSolver
+
+    g = golden(fname)
+    kw = {k[3:]: (g[k].tolist() if g[k].ndim else g[k].item()) for k in g.files if k.startswith("kw_")}
+    runs = {}
+    for ahead in ("0", "1"):
+        monkeypatch.setenv("DOTS_RHS_AHEAD", ahead)
+        alm = AlmSolver(int(g["n_time"]), geom_of(g), **kw)
+        for _ in range(kw["nit"]):
+            if alm.iterate():
+                break
+        started, confirmed = alm.dev.debug_counter(2), alm.dev.debug_counter(3)
+        sol, hist = alm.finalize()
+        alm.close()
+        runs[ahead] = (sol, hist.kkt_errors.copy(), hist.kkt_iteration.copy(), started, confirmed)
+    assert runs["0"][3] == 0 and runs["1"][3] >= 5 and runs["1"][4] == runs["1"][3]
+    assert int(runs["1"][2][-1]) == int(g["last_iteration"])
+    assert np.array_equal(runs["0"][1], runs["1"][1], equal_nan=True) and np.array_equal(runs["0"][2], runs["1"][2])
+    for k in runs["0"][0]:
+        if k != "checkpoints":
+            assert np.array_equal(runs["0"][0][k], runs["1"][0][k]), k
+
+
 @pytest.mark.skipif(os.environ.get("DOTS_SPIN_FETCH") == "0", reason="the mailbox is switched off")
 def test_mailbox_fallback_never_returns_stale_sums():
     """when the mailbox's sequence number does not arrive (here: every third hand-over is published with a wrong
