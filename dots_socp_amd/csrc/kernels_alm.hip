@@ -543,7 +543,7 @@ __global__ __launch_bounds__(RHS_NB2) void k_rhs_modes2(Dev d, double r, double 
 // once per corner VERTEX; the caches catch little of that beside the beta_mid stream (PMC at torus100k: 2.25 GB read for
 // 1.50 GB algorithmic).  Here a triangle's rows are read once per tile that touches it (~1.6 tiles), and B serves both halves.
 // Vertex for vertex and corner for corner the arithmetic of rhs_value2 / soc_element2: results are bit-identical.
-constexpr int TILE2 = 512, TILE2_NB = 256;
+constexpr int TILE2_NB = 256;      // (a tile of k_rhs_soc_tiles: 512 (vertex, time) elements, two per lane)
 template <bool WITH_SOC>
 __global__ __launch_bounds__(TILE2_NB) void k_rhs_soc_tiles(Dev d, TileDev tl, double r, double eps, double *__restrict__ bhat, int IC, double sz, double cd) {
     extern __shared__ double tm_lds[];

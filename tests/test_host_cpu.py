@@ -53,16 +53,17 @@ def test_struct_layouts_match_the_header(tmp_path):
     src = tmp_path / "probe.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "dots_socp_hip.h"\n'
-        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(dots_problem_desc), sizeof(dots_params),"
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(dots_problem_desc), sizeof(dots_params),"
         " sizeof(dots_step_stats), sizeof(dots_mg_level), sizeof(dots_mg_desc), offsetof(dots_params, cg_tol),"
-        " offsetof(dots_mg_level, ap_val_p), sizeof(dots_front_desc), offsetof(dots_front_desc, values)); return 0;}\n"
+        " offsetof(dots_mg_level, ap_val_p), sizeof(dots_front_desc), offsetof(dots_front_desc, values),"
+        " sizeof(dots_penalty_policy), offsetof(dots_penalty_policy, factor)); return 0;}\n"
     )
     exe = tmp_path / "probe"
     assert os.system(f"gcc -I{ROOT}/include {src} -o {exe}") == 0
     out = os.popen(str(exe)).read().split()
     want = [ctypes.sizeof(_lib.ProblemDesc), ctypes.sizeof(_lib.Params), ctypes.sizeof(_lib.StepStats),
             ctypes.sizeof(_lib.MgLevel), ctypes.sizeof(_lib.MgDesc), _lib.Params.cg_tol.offset, _lib.MgLevel.ap_val_p.offset,
-            ctypes.sizeof(_lib.FrontDesc), _lib.FrontDesc.values.offset]
+            ctypes.sizeof(_lib.FrontDesc), _lib.FrontDesc.values.offset, ctypes.sizeof(_lib.PenaltyPolicy), _lib.PenaltyPolicy.factor.offset]
     assert [int(x) for x in out] == want
 
 
