@@ -694,7 +694,7 @@ int kkt_sums(Ctx *c, uint32_t mask, double *sums) {
 int penalty_decision_ahead(Ctx *c, uint32_t mask, const double *sums) {
     const dots_penalty_policy &pp = c->penalty_policy;
     if ((mask & 15u) != 15u || c->d.slab || c->step_palm || !c->lazy_div || !c->zf_alt || c->rhs_ahead || c->carry_valid || !rhs_takes_soc(c) ||
-        !rhs_divides(c) || c->pending_div != 0.0)
+        !rhs_divides(c) || c->pending_div != 0.0 || !carry_possible(c))      // (carry_possible: dots_adjust_penalty will leave the division pending)
         return 0;
     double o[2 * DOTS_N_KKT];
     int rc = kkt_combine(c, 15u, sums, o);
