@@ -1137,6 +1137,15 @@ int dots_front_setup(dots_ctx *c, const dots_front_desc *desc) {
     if ((rc = front_setup(c, desc))) return rc;
     // DOTS_STEP_CARRY: the per-corner gathers steps 2+3 leave for the next right-hand side / projection (one GPU, pitch <= 128);
     // they belong to the direct solver's iteration and are released with the factor
+    {   // beta_mid streamed around the caches (ql2_lane<BMNT>): where the factor can live in the Infinity Cache but factor + the state an iteration
+        // touches cannot.  Fitted on knot (everything fits: -2 % with the hint), sphere10k / knot63 (+6 % / see the study), torus100k, T = 127 (nothing fits: 0, -2 %)
+        const double mall = 256.0 * 1048576.0, F8 = 8.0 * (double)c->d.F * (double)c->d.TP, V8 = 8.0 * (double)c->d.V * (double)c->d.TP;
+        const double touched = 33.0 * F8 + 12.0 * V8;      // beta_mid, B, E, the carried sums; the vertex arrays
+        int nt = -1;
+        if (!env_int("DOTS_BM_NT", 0, 1, &nt)) { front_release(c); return DOTS_ERR_ARGUMENT; }
+        const double factor = 0.5 * c->front_bytes;      // what the sweeps touch: every block is read by both sweeps (the zero blocks of merged nodes are never read)
+        c->bm_nt = nt >= 0 ? nt : (factor < 0.85 * mall && factor + touched > mall ? 1 : 0);
+    }
     if (c->d.TP <= 128 && c->carry_arrays && c->d.nl > 0) {      // (one GPU or a time slab with nodes)
         const int64_t rows = (int64_t)3 * c->d.F;
         const double *sq = nullptr, *g = nullptr, *lo = nullptr, *e = nullptr;

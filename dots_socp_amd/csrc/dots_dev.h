@@ -339,6 +339,7 @@ struct Ctx {
     // reference).  Every other entry point that reads or writes those arrays first carries the division out (flush_division).
     double pending_div = 0.0;     // 0: none
     int lazy_div = 1;             // DOTS_LAZY_DIV=0: divide at once (A/B measurements)
+    int bm_nt = 0;                // steps 2+3 stream beta_mid with the non-temporal hint (decided by dots_front_setup: see ql2_lane; DOTS_BM_NT = 0 / 1 overrides)
     int step_kkt = 0;             // dots_step_flags: steps 2+3 also form the KKT sums they hold in registers (kkt_fused)
     KktFused kkt_fused{};         // their per-workgroup partial sums (own buffer: d.partials serves the other reductions)
     int64_t kkt_fused_cap_v = 0, kkt_fused_cap_f = 0;   // workgroups the buffers hold per slot

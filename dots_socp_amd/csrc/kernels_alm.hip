@@ -857,7 +857,10 @@ __global__ __launch_bounds__(BLOCK) void k_q_lambda_mult_triangle(Dev d, double 
 constexpr int CARRY_NB = 192;         // 3 wavefronts: 2 * 192 / TP rows = whole triangles for every pitch <= 128
 constexpr int CARRY_VALUES = 18;      // per lane: 3 corners x (2 halves + 1 divergence share) x 2 nodes
 // KKT: the lane also accumulates the sums of kkt_triangle_body2 that need no gather (ks[KF_N]; sz = scale_factor_z).
-template <int ZMODE, bool QONLY, bool CARRY, bool KKT = false, bool DIV = false>
+// BMNT: beta_mid is loaded and stored with the non-temporal hint (Ctx::bm_nt: where the factor can live in the 256 MB Infinity Cache if the
+// 36 T F values of beta_mid that stream through every iteration do not displace it -- sphere10k: 5 130-5 190 -> 5 490-5 500 it/s; where
+// everything fits (knot) the hint costs 2 %, where nothing does (torus100k) it changes nothing: profiles/studies/r04_nontemporal.txt)
+template <int ZMODE, bool QONLY, bool CARRY, bool KKT = false, bool DIV = false, bool BMNT = false>
 __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, double sB, double diag_in, double diag_bd, double tau, double *xl = nullptr,
                                          double sz = 0.0, double *ks = nullptr, double dv = 1.0) {
     const bool two = t + 1 < d.nl;                  // the second node exists (always, unless the slab holds an odd number of nodes)
@@ -879,8 +882,8 @@ __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, doub
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         phik[k] = ld2(d.phi + idxV(d, vk[k], t));
-        b0[k] = ld2(d.bm + idxM(d, f * 3 + k, 0, c, t));
-        b1[k] = ld2(d.bm + idxM(d, f * 3 + k, 1, c, t - 1));
+        b0[k] = BMNT ? ld2_nt(d.bm + idxM(d, f * 3 + k, 0, c, t)) : ld2(d.bm + idxM(d, f * 3 + k, 0, c, t));
+        b1[k] = BMNT ? ld2_nt(d.bm + idxM(d, f * 3 + k, 1, c, t - 1)) : ld2(d.bm + idxM(d, f * 3 + k, 1, c, t - 1));
         if (DIV) {      // (a pending penalty update: see soc_element)
             b0[k].v[0] /= dv; b0[k].v[1] /= dv;
             b1[k].v[0] /= dv; b1[k].v[1] /= dv;
@@ -991,8 +994,13 @@ __device__ __forceinline__ void ql2_lane(const Dev &d, int f, int c, int t, doub
         st2(d.E + ie, En);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            st2(d.bm_st + idxM(d, f * 3 + k, 0, c, t), n0[k]);
-            st2(d.bm_st + idxM(d, f * 3 + k, 1, c, t - 1), n1[k]);
+            if (BMNT) {
+                st2_nt(d.bm_st + idxM(d, f * 3 + k, 0, c, t), n0[k]);
+                st2_nt(d.bm_st + idxM(d, f * 3 + k, 1, c, t - 1), n1[k]);
+            } else {
+                st2(d.bm_st + idxM(d, f * 3 + k, 0, c, t), n0[k]);
+                st2(d.bm_st + idxM(d, f * 3 + k, 1, c, t - 1), n1[k]);
+            }
         }
     } else {      // only the first node of the pair exists: element-wise stores
         const bool has0 = t < d.ni, has1 = has1_0;
@@ -1159,7 +1167,7 @@ __device__ __forceinline__ void store_fused(const double (&v)[N], const int (&sl
 #pragma unroll
     for (int i = 0; i < N; ++i) part[(int64_t)(slot[i] - first) * nblk + bid] = v[i];
 }
-template <int ZMODE, bool KKT = false, bool DIV = false>
+template <int ZMODE, bool KKT = false, bool DIV = false, bool BMNT = false>
 __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carry(Dev d, double sz, double tau, int n_fwg, int tri_per_wg, double cd, double cr,
                                                                                   KktArgs ka, KktFused kf, double dv, int emit) {
     // emit: bit 0 the gathers of the next right-hand side / projection (cn_sq, cn_g: DOTS_STEP_CARRY), bit 1 those of this
@@ -1184,7 +1192,7 @@ __global__ __launch_bounds__(CARRY_NB) CARRY_OCCUPANCY void k_q_lambda_mult_carr
     const int j = active ? d.cpos[f * 3 + c] : 0; // row of this lane's corner k = c in the carried arrays (loaded with the lane's other constants)
 #endif
     double kt[KF_N] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (active) ql2_lane<ZMODE, false, true, KKT, DIV>(d, f, c, t, sz * INV_SQRT3, 1.0 + 2.0 * sz * sz, 1.0 + sz * sz, tau, xs + tid, sz, kt, dv);
+    if (active) ql2_lane<ZMODE, false, true, KKT, DIV, BMNT>(d, f, c, t, sz * INV_SQRT3, 1.0 + 2.0 * sz * sz, 1.0 + sz * sz, tau, xs + tid, sz, kt, dv);
     __syncthreads();
     const int L = d.TP >> 1;                      // lanes per row
     const int t0 = tid - c * L;                   // the lane of component 0 of this triangle and column
@@ -1296,8 +1304,13 @@ int launch_q_lambda_mult(Ctx *c, int zmid_mode, double dv) {
         if (defer) { dk.B_st = c->B_alt; dk.bm_st = c->d.zm; }
 #define CARRY_LAUNCH(Z, K)                                                                                                                                     \
     do {                                                                                                                                                     \
-        if (dv != 0.0) hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, true>), g, dim3(CARRY_NB), 0, c->stream, dk, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, dv, emit); \
-        else hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, false>), g, dim3(CARRY_NB), 0, c->stream, dk, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, 1.0, emit);        \
+        if (c->bm_nt) {                                                                                                                                      \
+            if (dv != 0.0) hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, true, true>), g, dim3(CARRY_NB), 0, c->stream, dk, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, dv, emit); \
+            else hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, false, true>), g, dim3(CARRY_NB), 0, c->stream, dk, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, 1.0, emit);        \
+        } else {                                                                                                                                             \
+            if (dv != 0.0) hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, true, false>), g, dim3(CARRY_NB), 0, c->stream, dk, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, dv, emit); \
+            else hipLaunchKernelGGL((k_q_lambda_mult_carry<Z, K, false, false>), g, dim3(CARRY_NB), 0, c->stream, dk, p.scale_z, p.tau, n_fwg, tw, cd, cr, ka, kf, 1.0, emit);        \
+        }                                                                                                                                                    \
     } while (0)
         if (zmid_mode == 2) CARRY_LAUNCH(2, false);
         else if (defer && k) CARRY_LAUNCH(2, true);
@@ -1599,6 +1612,8 @@ void preload_alm_kernels() {
         (const void *)k_q_lambda_mult_carry<1>, (const void *)k_q_lambda_mult_carry<2>, (const void *)k_q_lambda_mult_carry<1, true>,
         (const void *)k_q_lambda_mult_carry<1, false, true>, (const void *)k_q_lambda_mult_carry<2, false, true>, (const void *)k_q_lambda_mult_carry<1, true, true>,
         (const void *)k_q_lambda_mult_carry<2, true, false>, (const void *)k_q_lambda_mult_carry<2, true, true>, (const void *)k_rebuild_zmid,
+        (const void *)k_q_lambda_mult_carry<2, false, false, true>, (const void *)k_q_lambda_mult_carry<2, false, true, true>,
+        (const void *)k_q_lambda_mult_carry<2, true, false, true>, (const void *)k_q_lambda_mult_carry<2, true, true, true>,
 
         (const void *)k_divide_five, (const void *)k_scale, (const void *)k_divide, (const void *)k_rebuild_mu, (const void *)k_rebuild_E,
     };
