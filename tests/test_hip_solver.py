@@ -322,7 +322,10 @@ def test_penalty_decision_ahead_of_the_host(fname, monkeypatch):
         sol, hist = alm.finalize()
         alm.close()
         runs[ahead] = (sol, hist.kkt_errors.copy(), hist.kkt_iteration.copy(), started, confirmed)
-    assert runs["0"][3] == 0 and runs["1"][3] >= 5 and runs["1"][4] == runs["1"][3]
+    if os.environ.get("DOTS_CARRY", "1") != "0" and os.environ.get("DOTS_LAZY_DIV", "1") != "0":      # the decision ahead needs both (A/B switches)
+        assert runs["0"][3] == 0 and runs["1"][3] >= 5 and runs["1"][4] == runs["1"][3]
+    else:
+        assert runs["0"][3] == 0 and runs["1"][3] == 0
     assert int(runs["1"][2][-1]) == int(g["last_iteration"])
     assert np.array_equal(runs["0"][1], runs["1"][1], equal_nan=True) and np.array_equal(runs["0"][2], runs["1"][2])
     for k in runs["0"][0]:
