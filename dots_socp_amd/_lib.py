@@ -130,7 +130,7 @@ SLAB_SIZES = {"vertex_halo": 0, "b_chunk": 1, "x_chunk": 2, "triangle_halo": 3}
 KNOWN_ENV = {
     # read by the library (csrc/dots_api.hip: env_int)
     "DOTS_CG_STAGE_LDS", "DOTS_MG_TAIL_ROWS", "DOTS_SOC_WITH_RHS", "DOTS_QL_TWO", "DOTS_KKT_TWO", "DOTS_RHS_TWO", "DOTS_RHS_TILES", "DOTS_CARRY", "DOTS_CARRY_MIN", "DOTS_BM_NT", "DOTS_LAZY_DIV", "DOTS_ZMID_DEFER", "DOTS_MEM_BUDGET", "DOTS_SPIN_FETCH",
-    "DOTS_FRONT_VEC2", "DOTS_FRONT_RB", "DOTS_FRONT_ROWS", "DOTS_FRONT_XCD", "DOTS_FRONT_TUNE", "DOTS_FRONT_CFG", "DOTS_MAIL_TEST_DROP",
+    "DOTS_FRONT_VEC2", "DOTS_FRONT_RB", "DOTS_FRONT_ROWS", "DOTS_FRONT_XCD", "DOTS_FRONT_LEAFINV", "DOTS_FRONT_TUNE", "DOTS_FRONT_CFG", "DOTS_MAIL_TEST_DROP",
     "DOTS_MAIL_SPINS", "DOTS_ND_PCA_MIN",
     # read by the host side
     "DOTS_RHS_AHEAD", "DOTS_TIME_EVERY", "DOTS_FRONT_BANDS", "DOTS_FRONT_TOPINV", "DOTS_TORCH_FIRST", "DOTS_DIST_BACKEND", "DOTS_HIPCC_FLAGS",

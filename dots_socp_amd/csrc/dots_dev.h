@@ -157,6 +157,13 @@ struct FrontWork {
                               // the columns [lo, end) (a node that stores an explicit inverse), 0 = up to the diagonal
     int pad;
 };
+// One leaf of the tree when the leaves' band is stored as explicit local inverses (kernels_front.hip: k_front_leaf_fwd / _bwd)
+struct LeafWork {
+    int k0, n, b, pad;        // first sweep-order index (= device vertex: identity numbering only), separator / boundary rows
+    int64_t soff;             // first entry of S = A_ss^-1 (n x n, row-major) in FrontDev::leafS
+    int64_t bdoff;            // first boundary row in bd_vertex / cmap
+    int64_t parent_w;         // first row of the plane this leaf writes in its parent's W
+};
 // One original node inside a merged band node (k_merge_member builds F' from the members' own blocks)
 struct MergeMember {
     int n, b;                 // its separator / boundary rows
@@ -190,6 +197,9 @@ struct FrontDev {
     const double *F = nullptr;            // original blocks, then the merged ones
     double *W = nullptr;                  // update planes [rows][TP]; entries no child writes stay zero
     const FrontWork *fwd_desc = nullptr, *bwd_desc = nullptr;             // per workgroup: node record + its block
+    const double *leafS = nullptr;        // leaves as explicit inverses: S_p = A_ss^-1 of every leaf, one after the other (n_leaves > 0)
+    const LeafWork *leaf_desc = nullptr;
+    int n_leaves = 0, leaf_nmax = 0;      // leaves handled by the leaf kernels (0: the band kernels take band 0), their largest n
 };
 
 // Layout of the device scalar block used by the PCG (all arrays have NC entries, NC <= 256).
@@ -310,6 +320,7 @@ struct Ctx {
     int mail_test_drop = 0;       // DOTS_MAIL_TEST_DROP=n (tests): every n-th evaluation publishes a wrong sequence number
     int front_rows = 1;           // row-per-lane-group sweep kernels on bands of short rows (DOTS_FRONT_ROWS: 0 never, 1 by rule, 2 wherever they fit)
     int front_xcd = 1;            // DOTS_FRONT_XCD=0: plain work-list order in the sweeps
+    int front_leafinv = 1;        // DOTS_FRONT_LEAFINV=0: the leaves keep [L^-1 ; G] blocks like every other node
     int front_tune = 0;           // DOTS_FRONT_TUNE=1 print the per-band timing table, 2 also apply the fastest choice
     int *h_flags = nullptr;
     int n_partial_blocks = 0;

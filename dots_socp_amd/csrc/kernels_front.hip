@@ -465,6 +465,114 @@ __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const
     }
 }
 
+// ---- the leaves as explicit local inverses ------------------------------------------------------------------------------
+// A leaf p of the tree has no children: its front holds ORIGINAL matrix entries only, A_ss = K_ss + (sigma_a + eps) M_ss and the coupling
+// A_bs = K_bs -- sparse (a boundary vertex touches two or three vertices of the leaf) and the SAME for every mode (M is diagonal).  The band
+// kernels nevertheless stream the dense G_p = K_bs A_ss^-1 (b x n per mode: three quarters of a leaf's block, and the leaves' band is a fifth of the
+// factor on a large mesh).  Here a leaf stores S_p = A_ss^-1 = L^-T L^-1 (n x n per mode, k_top_inverse from its L^-1) and both sweeps take the
+// coupling from the CSR of K that the context holds anyway:
+//     forward    t = S_p b[sep_p]                       u_i = sum_{v in sep_p} K[bd_i, v] t_v        -> the leaf's plane of its parent
+//     backward   x[sep_p] = S_p (b[sep_p] - g),         g_j = sum_{u not in sep_p} K[sep_j, u] x_u   (every such u is a boundary vertex of the leaf)
+// n^2 entries per leaf, mode and sweep instead of n (n + 1) / 2 + b n (torus100k: 155 instead of 329 MB per sweep), no y of the leaves stored.
+// One workgroup per leaf; thread = (VEC modes, lane group); a lane group owns a row.  Needs the device numbering to be the sweep order
+// (FrontDev::vmap == nullptr: a vertex's position in its leaf is its index minus k0) and an un-merged band of leaves.
+template <int VEC>
+__device__ __forceinline__ Vd<VEC> leaf_row(const double *__restrict__ Si, const double *vsh, int n, int TP, int sh) {
+    Vd<VEC> acc;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc.v[c] = 0.0;
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+        Vd<VEC> s[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] = vload<VEC>(Si + ((int64_t)(j + u) << sh));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = vload<VEC>(vsh + (j + u) * TP);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) acc.v[c] += s[u].v[c] * v[u].v[c];
+    }
+    for (; j < n; ++j) {
+        const Vd<VEC> s0 = vload<VEC>(Si + ((int64_t)j << sh)), v0 = vload<VEC>(vsh + j * TP);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc.v[c] += s0.v[c] * v0.v[c];
+    }
+    return acc;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_front_leaf_fwd(FrontArgs g, FrontDev f, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                       const double *__restrict__ val, const double *__restrict__ bhat) {
+    extern __shared__ __attribute__((aligned(16))) double lsh[];      // w [n][TP], then t [n][TP]
+    const LeafWork lw = f.leaf_desc[blockIdx.x];
+    const int sh = g.sh, TP = g.TP, tid = threadIdx.x;
+    const int shv = VEC == 2 ? sh - 1 : sh;
+    const int a = (tid & ((1 << shv) - 1)) * VEC, grp = tid >> shv, NG = 256 >> shv;
+    const int n = lw.n, b = lw.b, k0 = lw.k0;
+    const bool live = a < g.ncol;
+    double *wsh = lsh + a, *tsh = lsh + n * TP + a;
+    if (live)
+        for (int j = grp; j < n; j += NG) vstore<VEC>(wsh + j * TP, vload<VEC>(bhat + ((int64_t)(k0 + j) << sh) + a));
+    __syncthreads();
+    const double *__restrict__ S = f.leafS + (lw.soff << sh) + a;
+    if (live)
+        for (int i = grp; i < n; i += NG) vstore<VEC>(tsh + i * TP, leaf_row<VEC>(S + (((int64_t)i * n) << sh), wsh, n, TP, sh));
+    __syncthreads();
+    if (!live) return;
+    for (int r = grp; r < b; r += NG) {
+        const int vb = f.bd_vertex[lw.bdoff + r];
+        const int cm = f.cmap[lw.bdoff + r];
+        Vd<VEC> acc;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc.v[c] = 0.0;
+        const int e1 = rowptr[vb + 1];
+        for (int e = rowptr[vb]; e < e1; ++e) {
+            const unsigned u = (unsigned)(col[e] - k0);
+            if (u < (unsigned)n) {
+                const double kv = val[e];
+                const Vd<VEC> t = vload<VEC>(tsh + (int)u * TP);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc.v[c] += kv * t.v[c];
+            }
+        }
+        vstore<VEC>(f.W + ((lw.parent_w + cm) << sh) + a, acc);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_front_leaf_bwd(FrontArgs g, FrontDev f, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                       const double *__restrict__ val, const double *__restrict__ bhat, double *X) {
+    extern __shared__ __attribute__((aligned(16))) double lsh[];      // b[sep] - g  [n][TP]
+    const LeafWork lw = f.leaf_desc[blockIdx.x];
+    const int sh = g.sh, TP = g.TP, tid = threadIdx.x;
+    const int shv = VEC == 2 ? sh - 1 : sh;
+    const int a = (tid & ((1 << shv) - 1)) * VEC, grp = tid >> shv, NG = 256 >> shv;
+    const int n = lw.n, k0 = lw.k0;
+    const bool live = a < g.ncol;
+    double *rsh = lsh + a;
+    if (live)
+        for (int j = grp; j < n; j += NG) {
+            const int v = k0 + j;
+            Vd<VEC> acc = vload<VEC>(bhat + ((int64_t)v << sh) + a);
+            const int e1 = rowptr[v + 1];
+            for (int e = rowptr[v]; e < e1; ++e) {
+                const int u = col[e];
+                if ((unsigned)(u - k0) >= (unsigned)n) {      // outside the leaf: a boundary vertex, solved by a launch of the bands above
+                    const double kv = val[e];
+                    const Vd<VEC> x = vload<VEC>(X + ((int64_t)u << sh) + a);
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) acc.v[c] -= kv * x.v[c];
+                }
+            }
+            vstore<VEC>(rsh + j * TP, acc);
+        }
+    __syncthreads();
+    if (!live) return;
+    const double *__restrict__ S = f.leafS + (lw.soff << sh) + a;
+    for (int i = grp; i < n; i += NG) vstore<VEC>(X + ((int64_t)(k0 + i) << sh) + a, leaf_row<VEC>(S + (((int64_t)i * n) << sh), rsh, n, TP, sh));
+}
+
 // ---- merged bands: F' of a merged node from its members' blocks (see the header comment) ---------------------
 struct MergeArgs {
     int sh, TP, ncol;
@@ -968,6 +1076,17 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     for (int k = 0; k < d.V && identity; ++k) identity = vmap[(size_t)k] == k;
     bool identity0 = true;
     for (int k = 0; k < d.V && identity0; ++k) identity0 = vmap0[(size_t)k] == k;
+    // The leaves as explicit local inverses (k_front_leaf_fwd / _bwd): an un-merged band of leaves below at least one other band; every leaf's
+    // vertices numbered as the sweeps walk them (device vertex = sweep-order index: the plan's own numbering, or any that keeps the leaves in place);
+    // a row of modes within a workgroup.  DOTS_FRONT_CFG / DOTS_FRONT_TUNE choose among the BAND kernels, also for band 0: the leaves then stay with them.
+    bool leaf_inv = c->front_leafinv && !getenv("DOTS_FRONT_CFG") && !c->front_tune && nb >= 2 && cuts[1] == 1 && d.rowptr && d.col && d.val &&
+                    (d.TP / (front_two_modes(c) ? 2 : 1)) <= 256;
+    for (size_t gi = 0; gi < groups.size() && leaf_inv; ++gi) {
+        const Group &G = groups[gi];
+        if (G.band != 0) continue;
+        if (G.n == 0 && G.b > 0) leaf_inv = false;      // (cannot happen: a leaf's boundary comes from its own vertices)
+        for (int j = 0; j < G.n && leaf_inv; ++j) leaf_inv = vmap[(size_t)(G.k0 + j)] == G.k0 + j;
+    }
     // planes: the band's bucket (0, 2, 4, 8) of m rows each per node; W starts with a few zero rows (woff = 0 is never read)
     int64_t wrows = 8;
     for (int k = 0; k < nb; ++k) {
@@ -1159,7 +1278,10 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         int64_t srows = 0;
         for (const FrontNode &nd : nodes) srows += (int64_t)nd.b * nd.b;
         const double per = 8.0 * (double)d.TP;
-        const double factor_b = per * (double)all_entries, work_b = h->values ? 0.0 : per * (double)(h->n_entries + srows);
+        double leaf_entries = 0.0;      // the leaves' explicit inverses, stored beside their blocks (see below)
+        if (leaf_inv)
+            for (int gi : by_band[0]) leaf_entries += (double)groups[(size_t)gi].n * groups[(size_t)gi].n;
+        const double factor_b = per * ((double)all_entries + leaf_entries), work_b = h->values ? 0.0 : per * (double)(h->n_entries + srows);
         const double carry_b = (c->d.TP <= 128 && c->carry_arrays) ? 8.0 * (c->shard_stride == 0 ? 12.0 : 9.0) * (double)c->d.F * (double)c->d.TP : 0.0;
         size_t free_b = 0, total_b = 0;
         DOTS_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1297,6 +1419,68 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     const double *w = nullptr;
     if ((rc = front_upload<double>(c, &w, nullptr, std::max<int64_t>(wrows, 1) << d.tp_shift))) { front_release(c); return rc; }
     f.W = const_cast<double *>(w);
+    // ---- the leaves as explicit local inverses (leaf_inv above; w and t of the largest leaf must fit the LDS a workgroup may take)
+    if (leaf_inv) {
+        std::vector<LeafWork> leaves;
+        std::vector<int64_t> foffs, ooffs;
+        std::vector<int> ns;
+        int64_t total = 0, biggest = 1;
+        int nmax = 0;
+        double saved_read = 0.0, saved_alg = 0.0;
+        for (int gi : by_band[0]) {
+            const Group &G = groups[(size_t)gi];
+            if (G.n == 0) continue;      // (nothing to eliminate: nothing to send either -- its plane stays zero)
+            LeafWork lw{};
+            lw.k0 = G.k0; lw.n = G.n; lw.b = G.b;
+            lw.soff = total;
+            lw.bdoff = h->node_uoff[G.root];
+            lw.parent_w = G.parent < 0 ? 0 : groups[(size_t)G.parent].woff + (int64_t)G.colour * (groups[(size_t)G.parent].n + groups[(size_t)G.parent].b);
+            if (G.parent < 0) lw.b = 0;
+            leaves.push_back(lw);
+            foffs.push_back(G.foff);
+            ooffs.push_back(total);
+            ns.push_back(G.n);
+            total += (int64_t)G.n * G.n;
+            biggest = std::max<int64_t>(biggest, (int64_t)G.n * G.n);
+            nmax = std::max(nmax, G.n);
+            saved_read += 0.5 * G.n * (G.n + 1.0) + (double)G.b * G.n - (double)G.n * G.n;
+            saved_alg += (double)G.b * G.n;
+        }
+        const size_t lds = sizeof(double) * 2 * (size_t)nmax * (size_t)d.TP;
+        if (!leaves.empty() && lds <= 48 * 1024) {
+            const double *dS = nullptr;
+            const LeafWork *dl = nullptr;
+            if ((rc = front_upload<double>(c, &dS, nullptr, total << d.tp_shift)) || (rc = front_upload(c, &dl, leaves.data(), (int64_t)leaves.size()))) { front_release(c); return rc; }
+            void *dfo = nullptr, *doo = nullptr, *dn = nullptr;
+            hipError_t e = hipMalloc(&dfo, sizeof(int64_t) * foffs.size());
+            if (e == hipSuccess) e = hipMalloc(&doo, sizeof(int64_t) * ooffs.size());
+            if (e == hipSuccess) e = hipMalloc(&dn, sizeof(int) * ns.size());
+            if (e == hipSuccess) e = hipMemcpyAsync(dfo, foffs.data(), sizeof(int64_t) * foffs.size(), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(doo, ooffs.data(), sizeof(int64_t) * ooffs.size(), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(dn, ns.data(), sizeof(int) * ns.size(), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) {
+                const int Q = 256 >> d.tp_shift;
+                const unsigned bx = (unsigned)std::min<int64_t>(std::max<int64_t>((biggest + std::max(Q, 1) - 1) / std::max(Q, 1), 1), 4096);
+                for (size_t at = 0; at < ns.size() && e == hipSuccess; at += 32768) {      // (grid.y is limited to 65535)
+                    TopInvArgs g{};
+                    g.sh = d.tp_shift; g.TP = d.TP; g.ncol = d.cg_ncol;
+                    g.F = Fall; g.out = const_cast<double *>(dS);
+                    g.foff = (const int64_t *)dfo + at; g.ooff = (const int64_t *)doo + at; g.n = (const int *)dn + at;
+                    hipLaunchKernelGGL(k_top_inverse, dim3(bx, (unsigned)std::min<size_t>(ns.size() - at, 32768)), dim3(256), 0, c->stream, g);
+                    e = hipGetLastError();
+                }
+            }
+            hipError_t e2 = hipStreamSynchronize(c->stream);
+            for (void *p2 : {dfo, doo, dn}) if (p2) (void)hipFree(p2);
+            if (e != hipSuccess || e2 != hipSuccess) { front_release(c); return hip_fail(e != hipSuccess ? e : e2, "leaf inverses", __FILE__, __LINE__); }
+            f.leafS = dS;
+            f.leaf_desc = dl;
+            f.n_leaves = (int)leaves.size();
+            f.leaf_nmax = nmax;
+            entries_read -= saved_read;          // n^2 per leaf and sweep instead of n (n + 1) / 2 + b n
+            entries_unmerged -= saved_alg;       // algorithmic: the symmetric S (n (n + 1) / 2), the coupling is the mode-independent CSR
+        }
+    }
     c->front_bytes = 2.0 * entries_read * d.cg_ncol * sizeof(double);
     c->front_bytes_unmerged = 2.0 * entries_unmerged * d.cg_ncol * sizeof(double);
     if (const char *e = getenv("DOTS_FRONT_CFG")) {      // "fwd:1024x2,256x4,r1,...;bwd:..." one entry per band (A/B measurements); rQ = row kernel, Q lane groups per row
@@ -1483,10 +1667,25 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     return 0;
 }
 
+// the leaves' band as explicit local inverses: one workgroup per leaf
+static void front_launch_leaves(Ctx *c, const FrontDev &f, bool forward, const double *bhat, double *x) {
+    const Dev &d = c->dcg;
+    const FrontArgs g{d.tp_shift, d.TP, d.cg_ncol};
+    const size_t lds = sizeof(double) * (forward ? 2 : 1) * (size_t)f.leaf_nmax * (size_t)d.TP;
+    if (front_two_modes(c)) {
+        if (forward) hipLaunchKernelGGL((k_front_leaf_fwd<2>), dim3(f.n_leaves), dim3(256), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat);
+        else hipLaunchKernelGGL((k_front_leaf_bwd<2>), dim3(f.n_leaves), dim3(256), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat, x);
+    } else {
+        if (forward) hipLaunchKernelGGL((k_front_leaf_fwd<1>), dim3(f.n_leaves), dim3(256), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat);
+        else hipLaunchKernelGGL((k_front_leaf_bwd<1>), dim3(f.n_leaves), dim3(256), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat, x);
+    }
+}
+
 int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
     const FrontDev &f = c->front;
     if (f.n_nodes == 0) { set_error("front_solve: no factor installed"); return DOTS_ERR_STATE; }
     for (int l = 0; l < f.n_levels; ++l) {
+        if (l == 0 && f.n_leaves > 0) { front_launch_leaves(c, f, true, bhat, x); continue; }
         const int n = c->front_fwd_ptr[l + 1] - c->front_fwd_ptr[l];
         // (a top band of explicit inverses writes the solution itself)
         double *out = (c->front_top_inverse && l == f.n_levels - 1) ? x : y;
@@ -1494,6 +1693,7 @@ int front_solve(Ctx *c, const double *bhat, double *y, double *x) {
         else if (n > 0) front_launch_fwd(c, f, f.fwd_desc + c->front_fwd_ptr[l], n, c->front_fwd_nb[l], c->front_fwd_rb[l], c->front_planes[l], bhat, out);
     }
     for (int l = f.n_levels - 1 - (c->front_top_inverse ? 1 : 0); l >= 0; --l) {
+        if (l == 0 && f.n_leaves > 0) { front_launch_leaves(c, f, false, bhat, x); continue; }
         const int n = c->front_bwd_ptr[l + 1] - c->front_bwd_ptr[l];
         if (n > 0) front_launch_bwd(c, f, f.bwd_desc + c->front_bwd_ptr[l], n, c->front_bwd_nb[l], c->front_bwd_cb[l], y, x);
     }

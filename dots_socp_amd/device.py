@@ -452,7 +452,7 @@ class DeviceProblem:
         info = (C.c_double * 4)()
         _lib.check(self.lib.dots_front_info(self._h, info), "dots_front_info")
         self.front_summary.update(bands=[int(x) for x in bands], top_inverse=bool(top_inverse), bytes_per_solve_one_block_per_node=float(info[0]),
-                                  bytes_per_solve_as_installed=float(info[1]))
+                                  bytes_per_solve_as_installed=float(info[1]), leaf_inverse=self.debug_counter(4) > 0)
         return self.front_summary
 
     def front_launches(self):

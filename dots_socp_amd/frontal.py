@@ -214,15 +214,19 @@ def _band_tops_full(diss: Dissection, n, b, lo, hi):
     return entries, (desc + n)[top], b[top]
 
 
-def band_entries(diss: Dissection, node_n, node_b, lo, hi):
+def band_entries(diss: Dissection, node_n, node_b, lo, hi, leaf_inverse=False):
     """(factor entries one sweep reads, front rows, vector entries the forward workgroups read) when the heights
     [lo, hi) are merged: a member's rows hold its own triangle plus the columns of its descendants inside the band, the
     top member's boundary rows all columns; every row block of a merged node reads the right-hand side and the update
-    planes of its columns (2, 4 or 8 planes for bands of 1, 2 or more heights above the leaves)."""
+    planes of its columns (2, 4 or 8 planes for bands of 1, 2 or more heights above the leaves).
+    ``leaf_inverse``: the band [0, 1) stored as explicit local inverses (n^2 entries per leaf; kernels_front.hip)."""
     n = np.asarray(node_n, dtype=np.int64)
     b = np.asarray(node_b, dtype=np.int64)
     entries, nm, bm = _band_tops_full(diss, n, b, lo, hi)
-    entries += int((bm * nm).sum())
+    if leaf_inverse and lo == 0 and hi == 1:
+        entries = int((nm * nm).sum())
+    else:
+        entries += int((bm * nm).sum())
     rows = int((nm + bm).sum())
     planes = 0 if lo == 0 else (2 if hi - lo == 1 else (4 if hi - lo == 2 else 8))
     rb = 4 if rows >= 4096 else (2 if rows >= 2048 else 1)

@@ -172,6 +172,7 @@ def test_merged_tree_heights_give_the_same_solution(mesh, kw, T, eps):
         assert s["top_inverse"] == top or bands is None
         if not s["top_inverse"]:     # (an explicit inverse is read once: n^2 entries instead of n (n + 1) / 2 twice)
             assert s["bytes_per_solve_as_installed"] >= s["bytes_per_solve_one_block_per_node"] * (1.0 - 1e-12)
+            assert not s["leaf_inverse"] or (len(s["bands"]) > 2 and s["bands"][1] == 1)
             if reorder == "nd":      # the planner's count of what the merged sweeps read = the device's own
                 import scipy.sparse as sp
 
@@ -181,7 +182,7 @@ def test_merged_tree_heights_give_the_same_solution(mesh, kw, T, eps):
                 K_ = sp.csr_matrix((p_.lap_val, p_.lap_col, p_.lap_rowptr), shape=(p_.n_vertices,) * 2)
                 nb_ = frontal.symbolic_native(d_, K_.indptr, K_.indices)[0]
                 n_ = np.diff(d_.sep_ptr)
-                e_ = sum(frontal.band_entries(d_, n_, nb_, int(lo), int(hi))[0] for lo, hi in zip(s["bands"][:-1], s["bands"][1:]))
+                e_ = sum(frontal.band_entries(d_, n_, nb_, int(lo), int(hi), leaf_inverse=s["leaf_inverse"])[0] for lo, hi in zip(s["bands"][:-1], s["bands"][1:]))
                 assert s["bytes_per_solve_as_installed"] == 2.0 * e_ * (T + 1) * 8
         launches[tag] = s["launches_per_solve"]
         st = dev.run_phase("laplacian")
@@ -241,6 +242,7 @@ def test_forward_kernel_variants_agree(mesh, kw, T, monkeypatch):
     groups = 64 // max(pitch // 2, 1)              # lane groups of a wavefront = the largest Q of the row kernel
     out = {}
     settings = [("rule", {}), ("fold", {"DOTS_FRONT_ROWS": "0"}), ("rows_everywhere", {"DOTS_FRONT_ROWS": "2"}),
+                ("leaves_in_band_kernels", {"DOTS_FRONT_LEAFINV": "0"}), ("unmerged_leaves_in_band_kernels", {"DOTS_FRONT_BANDS": "off", "DOTS_FRONT_LEAFINV": "0"}),
                 ("unmerged_rule", {"DOTS_FRONT_BANDS": "off"}), ("unmerged_fold", {"DOTS_FRONT_BANDS": "off", "DOTS_FRONT_ROWS": "0"})]
     for q in (1, 2, 4, 8):
         if q <= groups:      # (the leaf band always fits the row kernel: its rows hold <= 16 columns)
@@ -270,3 +272,36 @@ def test_forward_kernel_variants_agree(mesh, kw, T, monkeypatch):
     monkeypatch.setenv("DOTS_FRONT_ROWS", "7")
     with pytest.raises(_lib.HipLibraryError, match="DOTS_FRONT_ROWS"):
         make(geom, T, 1e-3, "nd")
+
+
+@pytest.mark.parametrize("mesh,kw,T,eps", [("sphere", dict(level=4), 15, 0.0), ("torus", dict(nu=72, nv=40), 31, 1e-3), ("knot", dict(nu=240, nv=10), 63, 0.0),
+                                           ("sphere", dict(level=3), 127, 1e-3), ("sphere", dict(level=3), 128, 1e-3), ("torus", dict(nu=30, nv=12), 5, 0.0)])
+def test_leaves_as_local_inverses(mesh, kw, T, eps, monkeypatch):
+    """Where the leaves' band is not merged, a leaf stores S = A_ss^-1 instead of [L^-1 ; G] and both sweeps take its coupling to the
+    boundary from the CSR of K (kernels_front.hip: k_front_leaf_fwd / _bwd; the leaf's front holds original matrix entries only, the
+    coupling is the same for every mode): n^2 instead of n (n + 1) / 2 + b n entries per leaf, mode and sweep, the same solution to
+    rounding, the same number of launches.  A mode pitch of 256 does not fit a leaf's vectors in LDS: the band kernels stay."""
+    geom, _ = meshes.example(mesh, **kw)
+    monkeypatch.setenv("DOTS_FRONT_BANDS", "off")
+    out, info = {}, {}
+    for tag in ("1", "0"):
+        monkeypatch.setenv("DOTS_FRONT_LEAFINV", tag)
+        dev = make(geom, T, eps, "nd")
+        s = dev.setup_frontal(eps=eps)
+        info[tag] = (s["leaf_inverse"], dev.debug_counter(4), s["launches_per_solve"], s["bytes_per_solve_as_installed"], s["bytes_per_solve_one_block_per_node"])
+        st = dev.run_phase("laplacian")
+        assert st.cg_not_converged == 0
+        phi = dev.download("phi")
+        assert np.all(np.isfinite(phi))
+        mass = dev.plan.mass_vert[np.argsort(dev.plan.perm_vert)]
+        out[tag] = gauge(phi, mass) if eps == 0.0 else phi
+        n_leaves = int(np.sum(dev.plan.dissection.height == 0))
+        dev.close()
+    assert info["0"][:2] == (False, 0)
+    if T == 128:
+        assert info["1"][:2] == (False, 0)
+    else:
+        assert info["1"][0] and info["1"][1] == n_leaves
+        assert info["1"][3] < info["0"][3] and info["1"][4] < info["0"][4] and info["1"][3] >= info["1"][4]
+    assert info["1"][2] == info["0"][2]
+    assert rel(out["1"], out["0"]) < 1e-11
