@@ -469,65 +469,97 @@ __global__ __launch_bounds__(NB) void k_front_bwd(FrontArgs g, FrontDev f, const
 // A leaf p of the tree has no children: its front holds ORIGINAL matrix entries only, A_ss = K_ss + (sigma_a + eps) M_ss and the coupling
 // A_bs = K_bs -- sparse (a boundary vertex touches two or three vertices of the leaf) and the SAME for every mode (M is diagonal).  The band
 // kernels nevertheless stream the dense G_p = K_bs A_ss^-1 (b x n per mode: three quarters of a leaf's block, and the leaves' band is a fifth of the
-// factor on a large mesh).  Here a leaf stores S_p = A_ss^-1 = L^-T L^-1 (n x n per mode, k_top_inverse from its L^-1) and both sweeps take the
-// coupling from the CSR of K that the context holds anyway:
+// factor on a large mesh).  Here a leaf stores S_p = A_ss^-1 = L^-T L^-1 (symmetric: its lower triangle packed by rows, k_top_inverse from its L^-1)
+// and both sweeps take the coupling from the CSR of K that the context holds anyway:
 //     forward    t = S_p b[sep_p]                       u_i = sum_{v in sep_p} K[bd_i, v] t_v        -> the leaf's plane of its parent
 //     backward   x[sep_p] = S_p (b[sep_p] - g),         g_j = sum_{u not in sep_p} K[sep_j, u] x_u   (every such u is a boundary vertex of the leaf)
-// n^2 entries per leaf, mode and sweep instead of n (n + 1) / 2 + b n (torus100k: 155 instead of 329 MB per sweep), no y of the leaves stored.
+// n (n + 1) / 2 entries per leaf, mode and sweep instead of n (n + 1) / 2 + b n (torus100k: 85 instead of 329 MB per sweep; a workgroup reads every
+// entry twice, as a row and as a column entry: the second time from its caches), no y of the leaves stored.
 // One workgroup per leaf; thread = (VEC modes, lane group); a lane group owns a row.  Needs the device numbering to be the sweep order
 // (FrontDev::vmap == nullptr: a vertex's position in its leaf is its index minus k0) and an un-merged band of leaves.
+// Row i of the symmetric S from its packed lower triangle P[i (i + 1) / 2 + j] (j <= i): the entries left of the diagonal are one run, those right of
+// it are column i of the rows below (every entry is one run of modes: the lanes of a group still load 16 consecutive bytes each).  The first
+// LEAF_PRE entries of the row are loaded into registers BEFORE the vector they multiply is staged (leaf_row_load: the factor streams from memory while
+// the workgroup gathers its right-hand side), the rest -- leaves of more than LEAF_PRE vertices: degenerate cuts only -- behind it.
+// (A/B on one box, -DDOTS_LEAF_PRE=16 / 8 / 4: torus100k solve 671 / 660 / 660 us -- 94 VGPRs and 5 waves per SIMD against ~60 and 8 --, torus65k_T127 1 422 / 1 426 / 1 424)
+#ifndef DOTS_LEAF_PRE
+#define DOTS_LEAF_PRE 8
+#endif
+constexpr int LEAF_PRE = DOTS_LEAF_PRE;
+__device__ __forceinline__ int64_t leaf_entry(int i, int j) { return j <= i ? (int64_t)i * (i + 1) / 2 + j : (int64_t)j * (j + 1) / 2 + i; }
 template <int VEC>
-__device__ __forceinline__ Vd<VEC> leaf_row(const double *__restrict__ Si, const double *vsh, int n, int TP, int sh) {
+__device__ __forceinline__ void leaf_row_load(Vd<VEC> (&s)[LEAF_PRE], const double *__restrict__ P, int i, int n, int sh) {
+#pragma unroll
+    for (int u = 0; u < LEAF_PRE; ++u) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) s[u].v[c] = 0.0;
+        if (u < n && i < n) s[u] = vload<VEC>(P + (leaf_entry(i, u) << sh));
+    }
+}
+template <int VEC>
+__device__ __forceinline__ Vd<VEC> leaf_row_dot(const Vd<VEC> (&s)[LEAF_PRE], const double *__restrict__ P, const double *vsh, int i, int n, int TP, int sh) {
     Vd<VEC> acc;
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc.v[c] = 0.0;
-    int j = 0;
-    for (; j + 4 <= n; j += 4) {
-        Vd<VEC> s[4], v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s[u] = vload<VEC>(Si + ((int64_t)(j + u) << sh));
+    for (int u = 0; u < LEAF_PRE; ++u)
+        if (u < n) {
+            const Vd<VEC> v = vload<VEC>(vsh + u * TP);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = vload<VEC>(vsh + (j + u) * TP);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) acc.v[c] += s[u].v[c] * v[u].v[c];
-    }
-    for (; j < n; ++j) {
-        const Vd<VEC> s0 = vload<VEC>(Si + ((int64_t)j << sh)), v0 = vload<VEC>(vsh + j * TP);
+            for (int c = 0; c < VEC; ++c) acc.v[c] += s[u].v[c] * v.v[c];
+        }
+    for (int j = LEAF_PRE; j < n; ++j) {
+        const Vd<VEC> s0 = vload<VEC>(P + (leaf_entry(i, j) << sh)), v0 = vload<VEC>(vsh + j * TP);
 #pragma unroll
         for (int c = 0; c < VEC; ++c) acc.v[c] += s0.v[c] * v0.v[c];
     }
     return acc;
 }
-
 template <int VEC>
-__global__ __launch_bounds__(256) void k_front_leaf_fwd(FrontArgs g, FrontDev f, const int *__restrict__ rowptr, const int *__restrict__ col,
+__device__ __forceinline__ Vd<VEC> leaf_row(const double *__restrict__ P, const double *vsh, int i, int n, int TP, int sh) {
+    Vd<VEC> s[LEAF_PRE];
+    leaf_row_load<VEC>(s, P, i, n, sh);
+    return leaf_row_dot<VEC>(s, P, vsh, i, n, TP, sh);
+}
+
+template <int VEC, int NB>
+__global__ __launch_bounds__(NB) void k_front_leaf_fwd(FrontArgs g, FrontDev f, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                        const double *__restrict__ val, const double *__restrict__ bhat) {
     extern __shared__ __attribute__((aligned(16))) double lsh[];      // w [n][TP], then t [n][TP]
     const LeafWork lw = f.leaf_desc[blockIdx.x];
     const int sh = g.sh, TP = g.TP, tid = threadIdx.x;
     const int shv = VEC == 2 ? sh - 1 : sh;
-    const int a = (tid & ((1 << shv) - 1)) * VEC, grp = tid >> shv, NG = 256 >> shv;
+    const int a = (tid & ((1 << shv) - 1)) * VEC, grp = tid >> shv, NG = NB >> shv;
     const int n = lw.n, b = lw.b, k0 = lw.k0;
     const bool live = a < g.ncol;
     double *wsh = lsh + a, *tsh = lsh + n * TP + a;
+    const double *__restrict__ S = f.leafS + (lw.soff << sh) + a;
+    Vd<VEC> srow[LEAF_PRE];
+    if (live) leaf_row_load<VEC>(srow, S, grp, n, sh);
+    // the first boundary row of this lane group: its vertex, where it goes in the parent's plane, its row of K (needed after the barriers)
+    const bool upd0 = grp < b, upd1 = grp + NG < b;
+    const int vb0 = upd0 ? f.bd_vertex[lw.bdoff + grp] : 0, cm0 = upd0 ? f.cmap[lw.bdoff + grp] : 0;
+    const int vb1 = upd1 ? f.bd_vertex[lw.bdoff + grp + NG] : 0, cm1 = upd1 ? f.cmap[lw.bdoff + grp + NG] : 0;
+    const int eb0 = upd0 ? rowptr[vb0] : 0, ee0 = upd0 ? rowptr[vb0 + 1] : 0;
+    const int eb1 = upd1 ? rowptr[vb1] : 0, ee1 = upd1 ? rowptr[vb1 + 1] : 0;
     if (live)
         for (int j = grp; j < n; j += NG) vstore<VEC>(wsh + j * TP, vload<VEC>(bhat + ((int64_t)(k0 + j) << sh) + a));
     __syncthreads();
-    const double *__restrict__ S = f.leafS + (lw.soff << sh) + a;
-    if (live)
-        for (int i = grp; i < n; i += NG) vstore<VEC>(tsh + i * TP, leaf_row<VEC>(S + (((int64_t)i * n) << sh), wsh, n, TP, sh));
+    if (live) {
+        if (grp < n) vstore<VEC>(tsh + grp * TP, leaf_row_dot<VEC>(srow, S, wsh, grp, n, TP, sh));
+        for (int i = grp + NG; i < n; i += NG) vstore<VEC>(tsh + i * TP, leaf_row<VEC>(S, wsh, i, n, TP, sh));
+    }
     __syncthreads();
     if (!live) return;
     for (int r = grp; r < b; r += NG) {
-        const int vb = f.bd_vertex[lw.bdoff + r];
-        const int cm = f.cmap[lw.bdoff + r];
+        const bool p0 = r == grp, p1 = r == grp + NG;
+        const int vb = p0 ? vb0 : (p1 ? vb1 : f.bd_vertex[lw.bdoff + r]);
+        const int cm = p0 ? cm0 : (p1 ? cm1 : f.cmap[lw.bdoff + r]);
         Vd<VEC> acc;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) acc.v[c] = 0.0;
-        const int e1 = rowptr[vb + 1];
-        for (int e = rowptr[vb]; e < e1; ++e) {
+        const int e1 = p0 ? ee0 : (p1 ? ee1 : rowptr[vb + 1]);
+        for (int e = p0 ? eb0 : (p1 ? eb1 : rowptr[vb]); e < e1; ++e) {
             const unsigned u = (unsigned)(col[e] - k0);
             if (u < (unsigned)n) {
                 const double kv = val[e];
@@ -540,17 +572,20 @@ __global__ __launch_bounds__(256) void k_front_leaf_fwd(FrontArgs g, FrontDev f,
     }
 }
 
-template <int VEC>
-__global__ __launch_bounds__(256) void k_front_leaf_bwd(FrontArgs g, FrontDev f, const int *__restrict__ rowptr, const int *__restrict__ col,
+template <int VEC, int NB>
+__global__ __launch_bounds__(NB) void k_front_leaf_bwd(FrontArgs g, FrontDev f, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                        const double *__restrict__ val, const double *__restrict__ bhat, double *X) {
     extern __shared__ __attribute__((aligned(16))) double lsh[];      // b[sep] - g  [n][TP]
     const LeafWork lw = f.leaf_desc[blockIdx.x];
     const int sh = g.sh, TP = g.TP, tid = threadIdx.x;
     const int shv = VEC == 2 ? sh - 1 : sh;
-    const int a = (tid & ((1 << shv) - 1)) * VEC, grp = tid >> shv, NG = 256 >> shv;
+    const int a = (tid & ((1 << shv) - 1)) * VEC, grp = tid >> shv, NG = NB >> shv;
     const int n = lw.n, k0 = lw.k0;
     const bool live = a < g.ncol;
     double *rsh = lsh + a;
+    const double *__restrict__ S = f.leafS + (lw.soff << sh) + a;
+    Vd<VEC> srow[LEAF_PRE];
+    if (live) leaf_row_load<VEC>(srow, S, grp, n, sh);
     if (live)
         for (int j = grp; j < n; j += NG) {
             const int v = k0 + j;
@@ -569,8 +604,8 @@ __global__ __launch_bounds__(256) void k_front_leaf_bwd(FrontArgs g, FrontDev f,
         }
     __syncthreads();
     if (!live) return;
-    const double *__restrict__ S = f.leafS + (lw.soff << sh) + a;
-    for (int i = grp; i < n; i += NG) vstore<VEC>(X + ((int64_t)(k0 + i) << sh) + a, leaf_row<VEC>(S + (((int64_t)i * n) << sh), rsh, n, TP, sh));
+    if (grp < n) vstore<VEC>(X + ((int64_t)(k0 + grp) << sh) + a, leaf_row_dot<VEC>(srow, S, rsh, grp, n, TP, sh));
+    for (int i = grp + NG; i < n; i += NG) vstore<VEC>(X + ((int64_t)(k0 + i) << sh) + a, leaf_row<VEC>(S, rsh, i, n, TP, sh));
 }
 
 // ---- merged bands: F' of a merged node from its members' blocks (see the header comment) ---------------------
@@ -633,6 +668,7 @@ struct TopInvArgs {
     double *out;                // S^-1 of every node of the list, one after the other
     const int64_t *foff, *ooff; // per node: its block in F, its block in out
     const int *n;
+    int packed;                 // 1: only the lower triangle is written, packed by rows (out[i (i + 1) / 2 + j], j <= i; ooff counts packed entries)
 };
 __global__ __launch_bounds__(256) void k_top_inverse(TopInvArgs g) {
     const int nd = blockIdx.y, n = g.n[nd];
@@ -644,6 +680,7 @@ __global__ __launch_bounds__(256) void k_top_inverse(TopInvArgs g) {
     const int64_t total = (int64_t)n * n;
     for (int64_t e = (int64_t)blockIdx.x * Q + q; e < total; e += (int64_t)gridDim.x * Q) {
         const int i = (int)(e / n), j = (int)(e % n);
+        if (g.packed && j > i) continue;
         double s0 = 0.0, s1 = 0.0;
         int k = max(i, j);
         for (; k + 2 <= n; k += 2) {
@@ -651,7 +688,7 @@ __global__ __launch_bounds__(256) void k_top_inverse(TopInvArgs g) {
             s1 += L[((int64_t)(k + 1) * n + i) << sh] * L[((int64_t)(k + 1) * n + j) << sh];
         }
         for (; k < n; ++k) s0 += L[((int64_t)k * n + i) << sh] * L[((int64_t)k * n + j) << sh];
-        S[e << sh] = s0 + s1;
+        S[(g.packed ? (int64_t)i * (i + 1) / 2 + j : e) << sh] = s0 + s1;
     }
 }
 
@@ -1080,7 +1117,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
     // vertices numbered as the sweeps walk them (device vertex = sweep-order index: the plan's own numbering, or any that keeps the leaves in place);
     // a row of modes within a workgroup.  DOTS_FRONT_CFG / DOTS_FRONT_TUNE choose among the BAND kernels, also for band 0: the leaves then stay with them.
     bool leaf_inv = c->front_leafinv && !getenv("DOTS_FRONT_CFG") && !c->front_tune && nb >= 2 && cuts[1] == 1 && d.rowptr && d.col && d.val &&
-                    (d.TP / (front_two_modes(c) ? 2 : 1)) <= 256;
+                    (d.TP / (front_two_modes(c) ? 2 : 1)) <= 1024;
     for (size_t gi = 0; gi < groups.size() && leaf_inv; ++gi) {
         const Group &G = groups[gi];
         if (G.band != 0) continue;
@@ -1280,7 +1317,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         const double per = 8.0 * (double)d.TP;
         double leaf_entries = 0.0;      // the leaves' explicit inverses, stored beside their blocks (see below)
         if (leaf_inv)
-            for (int gi : by_band[0]) leaf_entries += (double)groups[(size_t)gi].n * groups[(size_t)gi].n;
+            for (int gi : by_band[0]) leaf_entries += 0.5 * (double)groups[(size_t)gi].n * (groups[(size_t)gi].n + 1.0);
         const double factor_b = per * ((double)all_entries + leaf_entries), work_b = h->values ? 0.0 : per * (double)(h->n_entries + srows);
         const double carry_b = (c->d.TP <= 128 && c->carry_arrays) ? 8.0 * (c->shard_stride == 0 ? 12.0 : 9.0) * (double)c->d.F * (double)c->d.TP : 0.0;
         size_t free_b = 0, total_b = 0;
@@ -1440,10 +1477,10 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             foffs.push_back(G.foff);
             ooffs.push_back(total);
             ns.push_back(G.n);
-            total += (int64_t)G.n * G.n;
+            total += (int64_t)G.n * (G.n + 1) / 2;      // S is symmetric: its lower triangle, packed by rows
             biggest = std::max<int64_t>(biggest, (int64_t)G.n * G.n);
             nmax = std::max(nmax, G.n);
-            saved_read += 0.5 * G.n * (G.n + 1.0) + (double)G.b * G.n - (double)G.n * G.n;
+            saved_read += (double)G.b * G.n;
             saved_alg += (double)G.b * G.n;
         }
         const size_t lds = sizeof(double) * 2 * (size_t)nmax * (size_t)d.TP;
@@ -1466,6 +1503,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
                     g.sh = d.tp_shift; g.TP = d.TP; g.ncol = d.cg_ncol;
                     g.F = Fall; g.out = const_cast<double *>(dS);
                     g.foff = (const int64_t *)dfo + at; g.ooff = (const int64_t *)doo + at; g.n = (const int *)dn + at;
+                    g.packed = 1;
                     hipLaunchKernelGGL(k_top_inverse, dim3(bx, (unsigned)std::min<size_t>(ns.size() - at, 32768)), dim3(256), 0, c->stream, g);
                     e = hipGetLastError();
                 }
@@ -1477,8 +1515,8 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             f.leaf_desc = dl;
             f.n_leaves = (int)leaves.size();
             f.leaf_nmax = nmax;
-            entries_read -= saved_read;          // n^2 per leaf and sweep instead of n (n + 1) / 2 + b n
-            entries_unmerged -= saved_alg;       // algorithmic: the symmetric S (n (n + 1) / 2), the coupling is the mode-independent CSR
+            entries_read -= saved_read;          // n (n + 1) / 2 per leaf and sweep (the packed triangle of S) instead of n (n + 1) / 2 + b n;
+            entries_unmerged -= saved_alg;       // the coupling is the mode-independent CSR
         }
     }
     c->front_bytes = 2.0 * entries_read * d.cg_ncol * sizeof(double);
@@ -1672,13 +1710,19 @@ static void front_launch_leaves(Ctx *c, const FrontDev &f, bool forward, const d
     const Dev &d = c->dcg;
     const FrontArgs g{d.tp_shift, d.TP, d.cg_ncol};
     const size_t lds = sizeof(double) * (forward ? 2 : 1) * (size_t)f.leaf_nmax * (size_t)d.TP;
-    if (front_two_modes(c)) {
-        if (forward) hipLaunchKernelGGL((k_front_leaf_fwd<2>), dim3(f.n_leaves), dim3(256), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat);
-        else hipLaunchKernelGGL((k_front_leaf_bwd<2>), dim3(f.n_leaves), dim3(256), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat, x);
-    } else {
-        if (forward) hipLaunchKernelGGL((k_front_leaf_fwd<1>), dim3(f.n_leaves), dim3(256), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat);
-        else hipLaunchKernelGGL((k_front_leaf_bwd<1>), dim3(f.n_leaves), dim3(256), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat, x);
-    }
+    const bool v2 = front_two_modes(c);
+    const int lanes = d.TP / (v2 ? 2 : 1);
+    // (sixteen rows in flight per workgroup at every pitch -- 1024 threads at a pitch of 128 -- lose: torus65k_T127 110 / 87 -> 115 / 110 us per launch,
+    // one workgroup per CU instead of four; workgroups grow only where a row of modes needs more than 256 lanes)
+    const int nbt = lanes <= 256 ? 256 : (lanes <= 512 ? 512 : 1024);
+#define LEAF_LAUNCH(VECV, NBV)                                                                                                                       \
+    do {                                                                                                                                             \
+        if (forward) hipLaunchKernelGGL((k_front_leaf_fwd<VECV, NBV>), dim3(f.n_leaves), dim3(NBV), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat);      \
+        else hipLaunchKernelGGL((k_front_leaf_bwd<VECV, NBV>), dim3(f.n_leaves), dim3(NBV), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat, x);           \
+    } while (0)
+    if (v2) { if (nbt == 256) LEAF_LAUNCH(2, 256); else if (nbt == 512) LEAF_LAUNCH(2, 512); else LEAF_LAUNCH(2, 1024); }
+    else { if (nbt == 256) LEAF_LAUNCH(1, 256); else if (nbt == 512) LEAF_LAUNCH(1, 512); else LEAF_LAUNCH(1, 1024); }
+#undef LEAF_LAUNCH
 }
 
 int front_solve(Ctx *c, const double *bhat, double *y, double *x) {

@@ -219,12 +219,12 @@ def band_entries(diss: Dissection, node_n, node_b, lo, hi, leaf_inverse=False):
     [lo, hi) are merged: a member's rows hold its own triangle plus the columns of its descendants inside the band, the
     top member's boundary rows all columns; every row block of a merged node reads the right-hand side and the update
     planes of its columns (2, 4 or 8 planes for bands of 1, 2 or more heights above the leaves).
-    ``leaf_inverse``: the band [0, 1) stored as explicit local inverses (n^2 entries per leaf; kernels_front.hip)."""
+    ``leaf_inverse``: the band [0, 1) stored as explicit local inverses (n (n + 1) / 2 entries per leaf; kernels_front.hip)."""
     n = np.asarray(node_n, dtype=np.int64)
     b = np.asarray(node_b, dtype=np.int64)
     entries, nm, bm = _band_tops_full(diss, n, b, lo, hi)
     if leaf_inverse and lo == 0 and hi == 1:
-        entries = int((nm * nm).sum())
+        entries = int((nm * (nm + 1) // 2).sum())
     else:
         entries += int((bm * nm).sum())
     rows = int((nm + bm).sum())

@@ -279,7 +279,7 @@ def test_forward_kernel_variants_agree(mesh, kw, T, monkeypatch):
 def test_leaves_as_local_inverses(mesh, kw, T, eps, monkeypatch):
     """Where the leaves' band is not merged, a leaf stores S = A_ss^-1 instead of [L^-1 ; G] and both sweeps take its coupling to the
     boundary from the CSR of K (kernels_front.hip: k_front_leaf_fwd / _bwd; the leaf's front holds original matrix entries only, the
-    coupling is the same for every mode): n^2 instead of n (n + 1) / 2 + b n entries per leaf, mode and sweep, the same solution to
+    coupling is the same for every mode): n (n + 1) / 2 (S is symmetric) instead of n (n + 1) / 2 + b n entries per leaf, mode and sweep, the same solution to
     rounding, the same number of launches.  A mode pitch of 256 does not fit a leaf's vectors in LDS: the band kernels stay."""
     geom, _ = meshes.example(mesh, **kw)
     monkeypatch.setenv("DOTS_FRONT_BANDS", "off")
