@@ -574,7 +574,7 @@ int dots_create(const dots_problem_desc *desc, dots_ctx **out) {
         ok &= env_int("DOTS_FRONT_RB", 1, 4, &c->front_rb_max);
         ok &= env_int("DOTS_FRONT_ROWS", 0, 2, &c->front_rows);      // 0: the fold kernels everywhere, 1: row kernels where the rules say (default), 2: wherever they fit
         ok &= env_int("DOTS_FRONT_XCD", 0, 1, &c->front_xcd);
-        ok &= env_int("DOTS_FRONT_LEAFINV", 0, 1, &c->front_leafinv);
+        ok &= env_int("DOTS_FRONT_LEAFINV", 0, 2, &c->front_leafinv);
         ok &= env_int("DOTS_FRONT_TUNE", 0, 2, &c->front_tune);
         ok &= env_int("DOTS_MAIL_TEST_DROP", 0, 1 << 20, &c->mail_test_drop);
         int spins = -1;

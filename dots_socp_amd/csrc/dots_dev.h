@@ -159,10 +159,24 @@ struct FrontWork {
 };
 // One leaf of the tree when the leaves' band is stored as explicit local inverses (kernels_front.hip: k_front_leaf_fwd / _bwd)
 struct LeafWork {
-    int k0, n, b, pad;        // first sweep-order index (= device vertex: identity numbering only), separator / boundary rows
-    int64_t soff;             // first entry of S = A_ss^-1 (n x n, row-major) in FrontDev::leafS
+    int k0, n, b, pad;        // first sweep-order index (= device vertex: the leaf is numbered in place), separator / boundary rows
+    int64_t soff;             // first entry of S = A_ss^-1 (lower triangle packed by rows) in FrontDev::leafS
     int64_t bdoff;            // first boundary row in bd_vertex / cmap
     int64_t parent_w;         // first row of the plane this leaf writes in its parent's W
+    int64_t rowoff;           // first record of its boundary rows in FrontDev::leaf_bd
+};
+// The leaf's coupling to its boundary, copied once from the CSR of K into one record per row (the sweeps then reach it with ONE load
+// behind the leaf's record instead of vertex -> row pointer -> entries): entries in CSR order, so the sums are the CSR path's, bit for bit
+constexpr int LEAF_KC = 6, LEAF_KE = 8;
+struct LeafBdRow {            // boundary row: where it goes in the parent's plane, its entries inside the leaf (position in the leaf, value; padded with zeros)
+    int cm, cnt;
+    int u[LEAF_KC];
+    double v[LEAF_KC];
+};
+struct LeafSepRow {           // separator row (indexed by vertex): its entries OUTSIDE the leaf (vertex, value)
+    int cnt, pad;
+    int u[LEAF_KE];
+    double v[LEAF_KE];
 };
 // One original node inside a merged band node (k_merge_member builds F' from the members' own blocks)
 struct MergeMember {
@@ -199,6 +213,8 @@ struct FrontDev {
     const FrontWork *fwd_desc = nullptr, *bwd_desc = nullptr;             // per workgroup: node record + its block
     const double *leafS = nullptr;        // leaves as explicit inverses: S_p = A_ss^-1 of every leaf, one after the other (n_leaves > 0)
     const LeafWork *leaf_desc = nullptr;
+    const LeafBdRow *leaf_bd = nullptr;   // coupling records (nullptr: the leaf kernels walk the CSR)
+    const LeafSepRow *leaf_sep = nullptr;
     int n_leaves = 0, leaf_nmax = 0;      // leaves handled by the leaf kernels (0: the band kernels take band 0), their largest n
 };
 
@@ -320,7 +336,7 @@ struct Ctx {
     int mail_test_drop = 0;       // DOTS_MAIL_TEST_DROP=n (tests): every n-th evaluation publishes a wrong sequence number
     int front_rows = 1;           // row-per-lane-group sweep kernels on bands of short rows (DOTS_FRONT_ROWS: 0 never, 1 by rule, 2 wherever they fit)
     int front_xcd = 1;            // DOTS_FRONT_XCD=0: plain work-list order in the sweeps
-    int front_leafinv = 1;        // DOTS_FRONT_LEAFINV=0: the leaves keep [L^-1 ; G] blocks like every other node
+    int front_leafinv = 1;        // DOTS_FRONT_LEAFINV=0: the leaves keep [L^-1 ; G] blocks like every other node; 2: local inverses, coupling read from the CSR (no records)
     int front_tune = 0;           // DOTS_FRONT_TUNE=1 print the per-band timing table, 2 also apply the fastest choice
     int *h_flags = nullptr;
     int n_partial_blocks = 0;

@@ -522,7 +522,7 @@ __device__ __forceinline__ Vd<VEC> leaf_row(const double *__restrict__ P, const 
     return leaf_row_dot<VEC>(s, P, vsh, i, n, TP, sh);
 }
 
-template <int VEC, int NB>
+template <int VEC, int NB, bool TAB>
 __global__ __launch_bounds__(NB) void k_front_leaf_fwd(FrontArgs g, FrontDev f, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                        const double *__restrict__ val, const double *__restrict__ bhat) {
     extern __shared__ __attribute__((aligned(16))) double lsh[];      // w [n][TP], then t [n][TP]
@@ -536,12 +536,27 @@ __global__ __launch_bounds__(NB) void k_front_leaf_fwd(FrontArgs g, FrontDev f, 
     const double *__restrict__ S = f.leafS + (lw.soff << sh) + a;
     Vd<VEC> srow[LEAF_PRE];
     if (live) leaf_row_load<VEC>(srow, S, grp, n, sh);
-    // the first boundary row of this lane group: its vertex, where it goes in the parent's plane, its row of K (needed after the barriers)
+    // the first boundary row(s) of this lane group, loaded now and needed after the barriers: its record, or (no records) its vertex, where it
+    // goes in the parent's plane and its row of K
     const bool upd0 = grp < b, upd1 = grp + NG < b;
-    const int vb0 = upd0 ? f.bd_vertex[lw.bdoff + grp] : 0, cm0 = upd0 ? f.cmap[lw.bdoff + grp] : 0;
-    const int vb1 = upd1 ? f.bd_vertex[lw.bdoff + grp + NG] : 0, cm1 = upd1 ? f.cmap[lw.bdoff + grp + NG] : 0;
-    const int eb0 = upd0 ? rowptr[vb0] : 0, ee0 = upd0 ? rowptr[vb0 + 1] : 0;
-    const int eb1 = upd1 ? rowptr[vb1] : 0, ee1 = upd1 ? rowptr[vb1 + 1] : 0;
+    const LeafBdRow *__restrict__ br = TAB ? f.leaf_bd + lw.rowoff : nullptr;
+    int cm0 = 0, ru0[LEAF_KC];
+    double rv0[LEAF_KC];
+    int vb0 = 0, vb1 = 0, cm1 = 0, eb0 = 0, ee0 = 0, eb1 = 0, ee1 = 0;
+    if (TAB) {
+#pragma unroll
+        for (int k = 0; k < LEAF_KC; ++k) { ru0[k] = 0; rv0[k] = 0.0; }
+        if (upd0) {
+            cm0 = br[grp].cm;
+#pragma unroll
+            for (int k = 0; k < LEAF_KC; ++k) { ru0[k] = br[grp].u[k]; rv0[k] = br[grp].v[k]; }
+        }
+    } else {
+        vb0 = upd0 ? f.bd_vertex[lw.bdoff + grp] : 0; cm0 = upd0 ? f.cmap[lw.bdoff + grp] : 0;
+        vb1 = upd1 ? f.bd_vertex[lw.bdoff + grp + NG] : 0; cm1 = upd1 ? f.cmap[lw.bdoff + grp + NG] : 0;
+        eb0 = upd0 ? rowptr[vb0] : 0; ee0 = upd0 ? rowptr[vb0 + 1] : 0;
+        eb1 = upd1 ? rowptr[vb1] : 0; ee1 = upd1 ? rowptr[vb1 + 1] : 0;
+    }
     if (live)
         for (int j = grp; j < n; j += NG) vstore<VEC>(wsh + j * TP, vload<VEC>(bhat + ((int64_t)(k0 + j) << sh) + a));
     __syncthreads();
@@ -552,27 +567,43 @@ __global__ __launch_bounds__(NB) void k_front_leaf_fwd(FrontArgs g, FrontDev f, 
     __syncthreads();
     if (!live) return;
     for (int r = grp; r < b; r += NG) {
-        const bool p0 = r == grp, p1 = r == grp + NG;
-        const int vb = p0 ? vb0 : (p1 ? vb1 : f.bd_vertex[lw.bdoff + r]);
-        const int cm = p0 ? cm0 : (p1 ? cm1 : f.cmap[lw.bdoff + r]);
         Vd<VEC> acc;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) acc.v[c] = 0.0;
-        const int e1 = p0 ? ee0 : (p1 ? ee1 : rowptr[vb + 1]);
-        for (int e = p0 ? eb0 : (p1 ? eb1 : rowptr[vb]); e < e1; ++e) {
-            const unsigned u = (unsigned)(col[e] - k0);
-            if (u < (unsigned)n) {
-                const double kv = val[e];
-                const Vd<VEC> t = vload<VEC>(tsh + (int)u * TP);
+        int cm;
+        if (TAB) {      // (padded entries: value 0 at position 0 -- t is finite)
+            cm = cm0;
+            if (r != grp) {
+                cm = br[r].cm;
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) acc.v[c] += kv * t.v[c];
+                for (int k = 0; k < LEAF_KC; ++k) { ru0[k] = br[r].u[k]; rv0[k] = br[r].v[k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < LEAF_KC; ++k) {
+                const Vd<VEC> t = vload<VEC>(tsh + ru0[k] * TP);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc.v[c] += rv0[k] * t.v[c];
+            }
+        } else {
+            const bool p0 = r == grp, p1 = r == grp + NG;
+            const int vb = p0 ? vb0 : (p1 ? vb1 : f.bd_vertex[lw.bdoff + r]);
+            cm = p0 ? cm0 : (p1 ? cm1 : f.cmap[lw.bdoff + r]);
+            const int e1 = p0 ? ee0 : (p1 ? ee1 : rowptr[vb + 1]);
+            for (int e = p0 ? eb0 : (p1 ? eb1 : rowptr[vb]); e < e1; ++e) {
+                const unsigned u = (unsigned)(col[e] - k0);
+                if (u < (unsigned)n) {
+                    const double kv = val[e];
+                    const Vd<VEC> t = vload<VEC>(tsh + (int)u * TP);
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) acc.v[c] += kv * t.v[c];
+                }
             }
         }
         vstore<VEC>(f.W + ((lw.parent_w + cm) << sh) + a, acc);
     }
 }
 
-template <int VEC, int NB>
+template <int VEC, int NB, bool TAB>
 __global__ __launch_bounds__(NB) void k_front_leaf_bwd(FrontArgs g, FrontDev f, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                        const double *__restrict__ val, const double *__restrict__ bhat, double *X) {
     extern __shared__ __attribute__((aligned(16))) double lsh[];      // b[sep] - g  [n][TP]
@@ -590,14 +621,25 @@ __global__ __launch_bounds__(NB) void k_front_leaf_bwd(FrontArgs g, FrontDev f, 
         for (int j = grp; j < n; j += NG) {
             const int v = k0 + j;
             Vd<VEC> acc = vload<VEC>(bhat + ((int64_t)v << sh) + a);
-            const int e1 = rowptr[v + 1];
-            for (int e = rowptr[v]; e < e1; ++e) {
-                const int u = col[e];
-                if ((unsigned)(u - k0) >= (unsigned)n) {      // outside the leaf: a boundary vertex, solved by a launch of the bands above
-                    const double kv = val[e];
-                    const Vd<VEC> x = vload<VEC>(X + ((int64_t)u << sh) + a);
+            if (TAB) {
+                const LeafSepRow &R = f.leaf_sep[v];
+                const int cnt = R.cnt;
+                for (int k = 0; k < cnt; ++k) {
+                    const double kv = R.v[k];
+                    const Vd<VEC> x = vload<VEC>(X + ((int64_t)R.u[k] << sh) + a);
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) acc.v[c] -= kv * x.v[c];
+                }
+            } else {
+                const int e1 = rowptr[v + 1];
+                for (int e = rowptr[v]; e < e1; ++e) {
+                    const int u = col[e];
+                    if ((unsigned)(u - k0) >= (unsigned)n) {      // outside the leaf: a boundary vertex, solved by a launch of the bands above
+                        const double kv = val[e];
+                        const Vd<VEC> x = vload<VEC>(X + ((int64_t)u << sh) + a);
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) acc.v[c] -= kv * x.v[c];
+                    }
                 }
             }
             vstore<VEC>(rsh + j * TP, acc);
@@ -606,6 +648,44 @@ __global__ __launch_bounds__(NB) void k_front_leaf_bwd(FrontArgs g, FrontDev f, 
     if (!live) return;
     if (grp < n) vstore<VEC>(X + ((int64_t)(k0 + grp) << sh) + a, leaf_row_dot<VEC>(srow, S, rsh, grp, n, TP, sh));
     for (int i = grp + NG; i < n; i += NG) vstore<VEC>(X + ((int64_t)(k0 + i) << sh) + a, leaf_row<VEC>(S, rsh, i, n, TP, sh));
+}
+
+// the coupling records of every leaf from the CSR (once per factorisation); *overflow is set when a row holds more entries than a record
+__global__ __launch_bounds__(64) void k_leaf_tables(FrontDev f, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                                                   LeafBdRow *__restrict__ bt, LeafSepRow *__restrict__ st, int *overflow) {
+    const LeafWork lw = f.leaf_desc[blockIdx.x];
+    const int n = lw.n, k0 = lw.k0;
+    for (int r = threadIdx.x; r < lw.b; r += 64) {
+        LeafBdRow R{};
+        R.cm = f.cmap[lw.bdoff + r];
+        const int vb = f.bd_vertex[lw.bdoff + r];
+        int cnt = 0;
+        for (int e = rowptr[vb]; e < rowptr[vb + 1]; ++e) {
+            const unsigned u = (unsigned)(col[e] - k0);
+            if (u < (unsigned)n) {
+                if (cnt < LEAF_KC) { R.u[cnt] = (int)u; R.v[cnt] = val[e]; }
+                ++cnt;
+            }
+        }
+        if (cnt > LEAF_KC) atomicOr(overflow, 1);
+        R.cnt = cnt < LEAF_KC ? cnt : LEAF_KC;
+        bt[lw.rowoff + r] = R;
+    }
+    for (int j = threadIdx.x; j < n; j += 64) {
+        LeafSepRow R{};
+        const int v = k0 + j;
+        int cnt = 0;
+        for (int e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+            const int u = col[e];
+            if ((unsigned)(u - k0) >= (unsigned)n) {
+                if (cnt < LEAF_KE) { R.u[cnt] = u; R.v[cnt] = val[e]; }
+                ++cnt;
+            }
+        }
+        if (cnt > LEAF_KE) atomicOr(overflow, 1);
+        R.cnt = cnt < LEAF_KE ? cnt : LEAF_KE;
+        st[v] = R;
+    }
 }
 
 // ---- merged bands: F' of a merged node from its members' blocks (see the header comment) ---------------------
@@ -1461,7 +1541,7 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
         std::vector<LeafWork> leaves;
         std::vector<int64_t> foffs, ooffs;
         std::vector<int> ns;
-        int64_t total = 0, biggest = 1;
+        int64_t total = 0, biggest = 1, bd_rows = 0;
         int nmax = 0;
         double saved_read = 0.0, saved_alg = 0.0;
         for (int gi : by_band[0]) {
@@ -1471,8 +1551,10 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             lw.k0 = G.k0; lw.n = G.n; lw.b = G.b;
             lw.soff = total;
             lw.bdoff = h->node_uoff[G.root];
+            lw.rowoff = bd_rows;
             lw.parent_w = G.parent < 0 ? 0 : groups[(size_t)G.parent].woff + (int64_t)G.colour * (groups[(size_t)G.parent].n + groups[(size_t)G.parent].b);
             if (G.parent < 0) lw.b = 0;
+            bd_rows += lw.b;
             leaves.push_back(lw);
             foffs.push_back(G.foff);
             ooffs.push_back(total);
@@ -1515,6 +1597,21 @@ int front_setup(Ctx *c, const dots_front_desc *h) {
             f.leaf_desc = dl;
             f.n_leaves = (int)leaves.size();
             f.leaf_nmax = nmax;
+            if (c->front_leafinv == 1) {      // coupling records (a row with more entries than a record holds: the kernels walk the CSR instead)
+                const LeafBdRow *dbt = nullptr;
+                const LeafSepRow *dst = nullptr;
+                const int *dov = nullptr;
+                if ((rc = front_upload<LeafBdRow>(c, &dbt, nullptr, std::max<int64_t>(bd_rows, 1))) || (rc = front_upload<LeafSepRow>(c, &dst, nullptr, d.V)) ||
+                    (rc = front_upload<int>(c, &dov, nullptr, 1))) { front_release(c); return rc; }
+                hipLaunchKernelGGL(k_leaf_tables, dim3(f.n_leaves), dim3(64), 0, c->stream, f, d.rowptr, d.col, d.val, const_cast<LeafBdRow *>(dbt),
+                                   const_cast<LeafSepRow *>(dst), const_cast<int *>(dov));
+                int over = 0;
+                hipError_t e3 = hipGetLastError();
+                if (e3 == hipSuccess) e3 = hipMemcpyAsync(&over, dov, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                if (e3 == hipSuccess) e3 = hipStreamSynchronize(c->stream);
+                if (e3 != hipSuccess) { front_release(c); return hip_fail(e3, "leaf coupling records", __FILE__, __LINE__); }
+                if (!over) { f.leaf_bd = dbt; f.leaf_sep = dst; }
+            }
             entries_read -= saved_read;          // n (n + 1) / 2 per leaf and sweep (the packed triangle of S) instead of n (n + 1) / 2 + b n;
             entries_unmerged -= saved_alg;       // the coupling is the mode-independent CSR
         }
@@ -1714,15 +1811,22 @@ static void front_launch_leaves(Ctx *c, const FrontDev &f, bool forward, const d
     const int lanes = d.TP / (v2 ? 2 : 1);
     // (sixteen rows in flight per workgroup at every pitch -- 1024 threads at a pitch of 128 -- lose: torus65k_T127 110 / 87 -> 115 / 110 us per launch,
     // one workgroup per CU instead of four; workgroups grow only where a row of modes needs more than 256 lanes)
+#ifdef DOTS_LEAF_NB      // (A/B)
+    const int nbt = DOTS_LEAF_NB;
+#else
     const int nbt = lanes <= 256 ? 256 : (lanes <= 512 ? 512 : 1024);
-#define LEAF_LAUNCH(VECV, NBV)                                                                                                                       \
+#endif
+    const bool tab = f.leaf_bd != nullptr;
+#define LEAF_LAUNCH2(VECV, NBV, TABV)                                                                                                                \
     do {                                                                                                                                             \
-        if (forward) hipLaunchKernelGGL((k_front_leaf_fwd<VECV, NBV>), dim3(f.n_leaves), dim3(NBV), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat);      \
-        else hipLaunchKernelGGL((k_front_leaf_bwd<VECV, NBV>), dim3(f.n_leaves), dim3(NBV), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat, x);           \
+        if (forward) hipLaunchKernelGGL((k_front_leaf_fwd<VECV, NBV, TABV>), dim3(f.n_leaves), dim3(NBV), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat);      \
+        else hipLaunchKernelGGL((k_front_leaf_bwd<VECV, NBV, TABV>), dim3(f.n_leaves), dim3(NBV), lds, c->stream, g, f, d.rowptr, d.col, d.val, bhat, x);           \
     } while (0)
+#define LEAF_LAUNCH(VECV, NBV) do { if (tab) LEAF_LAUNCH2(VECV, NBV, true); else LEAF_LAUNCH2(VECV, NBV, false); } while (0)
     if (v2) { if (nbt == 256) LEAF_LAUNCH(2, 256); else if (nbt == 512) LEAF_LAUNCH(2, 512); else LEAF_LAUNCH(2, 1024); }
     else { if (nbt == 256) LEAF_LAUNCH(1, 256); else if (nbt == 512) LEAF_LAUNCH(1, 512); else LEAF_LAUNCH(1, 1024); }
 #undef LEAF_LAUNCH
+#undef LEAF_LAUNCH2
 }
 
 int front_solve(Ctx *c, const double *bhat, double *y, double *x) {

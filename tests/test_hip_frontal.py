@@ -280,11 +280,12 @@ def test_leaves_as_local_inverses(mesh, kw, T, eps, monkeypatch):
     """Where the leaves' band is not merged, a leaf stores S = A_ss^-1 instead of [L^-1 ; G] and both sweeps take its coupling to the
     boundary from the CSR of K (kernels_front.hip: k_front_leaf_fwd / _bwd; the leaf's front holds original matrix entries only, the
     coupling is the same for every mode): n (n + 1) / 2 (S is symmetric) instead of n (n + 1) / 2 + b n entries per leaf, mode and sweep, the same solution to
-    rounding, the same number of launches.  A mode pitch of 256 does not fit a leaf's vectors in LDS: the band kernels stay."""
+    rounding, the same number of launches; the coupling comes from per-row records copied from the CSR at setup (one load behind the leaf's
+    record) or from the CSR itself: bit-identical.  A mode pitch of 256 does not fit a leaf's vectors in LDS: the band kernels stay."""
     geom, _ = meshes.example(mesh, **kw)
     monkeypatch.setenv("DOTS_FRONT_BANDS", "off")
     out, info = {}, {}
-    for tag in ("1", "0"):
+    for tag in ("1", "0", "2"):      # 2: local inverses with the coupling read from the CSR instead of the per-row records
         monkeypatch.setenv("DOTS_FRONT_LEAFINV", tag)
         dev = make(geom, T, eps, "nd")
         s = dev.setup_frontal(eps=eps)
@@ -305,3 +306,4 @@ def test_leaves_as_local_inverses(mesh, kw, T, eps, monkeypatch):
         assert info["1"][3] < info["0"][3] and info["1"][4] < info["0"][4] and info["1"][3] >= info["1"][4]
     assert info["1"][2] == info["0"][2]
     assert rel(out["1"], out["0"]) < 1e-11
+    assert info["2"] == info["1"] and np.array_equal(out["2"], out["1"])      # the records hold the CSR's entries in its order
