@@ -1200,6 +1200,7 @@ int64_t dots_debug_counter(dots_ctx *c, int which) {
         case 2: return c->penalty_ahead_started;
         case 3: return c->penalty_ahead_confirmed;
         case 4: return c->front.n_leaves;      // leaves the sweeps handle as explicit local inverses (0: band kernels)
+        case 5: return c->front.leaf_bd ? 1 : 0;      // ... with their coupling in per-row records (0: read from the CSR)
         default: return -1;
     }
 }

@@ -290,6 +290,8 @@ def test_leaves_as_local_inverses(mesh, kw, T, eps, monkeypatch):
         dev = make(geom, T, eps, "nd")
         s = dev.setup_frontal(eps=eps)
         info[tag] = (s["leaf_inverse"], dev.debug_counter(4), s["launches_per_solve"], s["bytes_per_solve_as_installed"], s["bytes_per_solve_one_block_per_node"])
+        records = dev.debug_counter(5)
+        assert records == (1 if tag == "1" and s["leaf_inverse"] else 0)
         st = dev.run_phase("laplacian")
         assert st.cg_not_converged == 0
         phi = dev.download("phi")
@@ -307,3 +309,50 @@ def test_leaves_as_local_inverses(mesh, kw, T, eps, monkeypatch):
     assert info["1"][2] == info["0"][2]
     assert rel(out["1"], out["0"]) < 1e-11
     assert info["2"] == info["1"] and np.array_equal(out["2"], out["1"])      # the records hold the CSR's entries in its order
+
+
+def test_leaf_coupling_falls_back_to_the_csr_on_high_degree_vertices(monkeypatch):
+    """A bipyramid over a ring of 40 vertices, subdivided once: its two apices have 40 neighbours -- more than a coupling record of the leaf
+    kernels holds (LEAF_KC / LEAF_KE entries per row).  The setup notices it and the leaf kernels walk the CSR of K instead
+    (debug counter 5 = 0 with counter 4 > 0); the solution is the band kernels' one."""
+    m = 40
+    ang = 2.0 * np.pi * np.arange(m) / m
+    ring = np.stack([np.cos(ang), np.sin(ang), np.zeros(m)], axis=1)
+    v = np.concatenate([ring, [[0.0, 0.0, 0.9]], [[0.0, 0.0, -0.9]]])
+    t = []
+    for i in range(m):
+        j = (i + 1) % m
+        t += [(m, i, j), (m + 1, j, i)]
+    t = np.asarray(t)
+    # one midpoint subdivision (the apices keep their 40 neighbours)
+    edges = {}
+    vv = [tuple(x) for x in v]
+
+    def mid(a, b):
+        key = (min(a, b), max(a, b))
+        if key not in edges:
+            edges[key] = len(vv)
+            vv.append(tuple(0.5 * (np.asarray(vv[a]) + np.asarray(vv[b]))))
+        return edges[key]
+
+    tt = []
+    for a, b, c in t:
+        ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+        tt += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+    v, t = np.asarray(vv), np.asarray(tt)
+    mu = np.ones(v.shape[0])
+    mu0, mu1 = mu * (1.0 + v[:, 2]), mu * (1.0 - v[:, 2])
+    geom = dict(vertices=v, triangles=t, mu0=mu0 / mu0.sum(), mu1=mu1 / mu1.sum())
+    monkeypatch.setenv("DOTS_FRONT_BANDS", "off")
+    out, counters = {}, {}
+    for tag in ("1", "0"):
+        monkeypatch.setenv("DOTS_FRONT_LEAFINV", tag)
+        dev = make(geom, 15, 1e-2, "nd")
+        dev.setup_frontal(eps=1e-2)
+        counters[tag] = (dev.debug_counter(4), dev.debug_counter(5))
+        st = dev.run_phase("laplacian")
+        assert st.cg_not_converged == 0
+        out[tag] = dev.download("phi")
+        dev.close()
+    assert counters["1"][0] > 0 and counters["1"][1] == 0 and counters["0"] == (0, 0)
+    assert np.all(np.isfinite(out["1"])) and rel(out["1"], out["0"]) < 1e-11
