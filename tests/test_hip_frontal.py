@@ -19,10 +19,10 @@ def gauge(phi, mass):
     return phi - np.sum(phi * w) / np.sum(w)
 
 
-def make(geom, T, eps, reorder, seed=3):
+def make(geom, T, eps, reorder, seed=3, **kw):
     from dots_socp_amd.device import DeviceProblem
 
-    dev = DeviceProblem(T, geom, lap_solver="modal_pcg", reorder=reorder)
+    dev = DeviceProblem(T, geom, lap_solver="modal_pcg", reorder=reorder, **kw)
     rng = np.random.default_rng(seed)
     for name in ("A", "lambda_c", "mu", "B", "E"):
         dev.upload(name, rng.standard_normal(dev.shape(name)))
@@ -312,34 +312,24 @@ def test_leaves_as_local_inverses(mesh, kw, T, eps, monkeypatch):
 
 
 def test_leaf_coupling_falls_back_to_the_csr_on_high_degree_vertices(monkeypatch):
-    """A bipyramid over a ring of 40 vertices, subdivided once: its two apices have 40 neighbours -- more than a coupling record of the leaf
-    kernels holds (LEAF_KC / LEAF_KE entries per row).  The setup notices it and the leaf kernels walk the CSR of K instead
-    (debug counter 5 = 0 with counter 4 > 0); the solution is the band kernels' one."""
-    m = 40
-    ang = 2.0 * np.pi * np.arange(m) / m
-    ring = np.stack([np.cos(ang), np.sin(ang), np.zeros(m)], axis=1)
-    v = np.concatenate([ring, [[0.0, 0.0, 0.9]], [[0.0, 0.0, -0.9]]])
+    """A latitude-longitude sphere of 64 meridians (poles with 64 neighbours) cut into leaves of up to 48 vertices: a leaf next to a pole has a
+    boundary row with 8 entries inside the leaf -- more than a coupling record of the leaf kernels holds (LEAF_KC = 6).  The setup notices
+    it and the leaf kernels walk the CSR of K instead (debug counter 5 = 0 with counter 4 > 0); the solution is the band kernels' one."""
+    nlat, nlon = 12, 64
+    th = np.pi * np.arange(1, nlat + 1) / (nlat + 1)
+    ph = 2.0 * np.pi * np.arange(nlon) / nlon
+    rings = np.stack([np.outer(np.sin(th), np.cos(ph)), np.outer(np.sin(th), np.sin(ph)), np.outer(np.cos(th), np.ones(nlon))], axis=2).reshape(-1, 3)
+    v = np.concatenate([rings, [[0.0, 0.0, 1.0]], [[0.0, 0.0, -1.0]]])
+    north, south = nlat * nlon, nlat * nlon + 1
     t = []
-    for i in range(m):
-        j = (i + 1) % m
-        t += [(m, i, j), (m + 1, j, i)]
+    for j in range(nlon):
+        k = (j + 1) % nlon
+        t.append((north, j, k))
+        t.append((south, (nlat - 1) * nlon + k, (nlat - 1) * nlon + j))
+        for i in range(nlat - 1):
+            a0, a1, b0, b1 = i * nlon + j, i * nlon + k, (i + 1) * nlon + j, (i + 1) * nlon + k
+            t += [(a0, b0, a1), (a1, b0, b1)]
     t = np.asarray(t)
-    # one midpoint subdivision (the apices keep their 40 neighbours)
-    edges = {}
-    vv = [tuple(x) for x in v]
-
-    def mid(a, b):
-        key = (min(a, b), max(a, b))
-        if key not in edges:
-            edges[key] = len(vv)
-            vv.append(tuple(0.5 * (np.asarray(vv[a]) + np.asarray(vv[b]))))
-        return edges[key]
-
-    tt = []
-    for a, b, c in t:
-        ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
-        tt += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
-    v, t = np.asarray(vv), np.asarray(tt)
     mu = np.ones(v.shape[0])
     mu0, mu1 = mu * (1.0 + v[:, 2]), mu * (1.0 - v[:, 2])
     geom = dict(vertices=v, triangles=t, mu0=mu0 / mu0.sum(), mu1=mu1 / mu1.sum())
@@ -347,7 +337,7 @@ def test_leaf_coupling_falls_back_to_the_csr_on_high_degree_vertices(monkeypatch
     out, counters = {}, {}
     for tag in ("1", "0"):
         monkeypatch.setenv("DOTS_FRONT_LEAFINV", tag)
-        dev = make(geom, 15, 1e-2, "nd")
+        dev = make(geom, 15, 1e-2, "nd", nd_leaf=48)
         dev.setup_frontal(eps=1e-2)
         counters[tag] = (dev.debug_counter(4), dev.debug_counter(5))
         st = dev.run_phase("laplacian")
