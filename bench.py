@@ -426,16 +426,12 @@ def kernel_digest():
 def launch_ranks(args):
     """``python bench.py --gpus N`` without a launcher: start the N ranks (one per GPU) before anything in this process touches
     the GPU, let rank 0's JSON line through, return the ranks' exit code."""
-    import socket
-
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher picks a free rendezvous port itself (no bind-and-close race), on the loopback address
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           os.path.abspath(__file__)] + sys.argv[1:]
     # rank 0 prints the one JSON line; anything else the ranks write to stdout (gloo announces its connections there) goes to stderr
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = proc.stdout.splitlines()
