@@ -1138,14 +1138,17 @@ int dots_front_setup(dots_ctx *c, const dots_front_desc *desc) {
     if ((rc = front_setup(c, desc))) return rc;
     // DOTS_STEP_CARRY: the per-corner gathers steps 2+3 leave for the next right-hand side / projection (one GPU, pitch <= 128);
     // they belong to the direct solver's iteration and are released with the factor
-    {   // beta_mid streamed around the caches (ql2_lane<BMNT>): where the factor can live in the Infinity Cache but factor + the state an iteration
-        // touches cannot.  Fitted on knot (everything fits: -2 % with the hint), sphere10k / knot63 (+6 % / see the study), torus100k, T = 127 (nothing fits: 0, -2 %)
+    {   // beta_mid streamed around the caches (ql2_lane<BMNT>): where factor + the state an iteration touches do not fit the Infinity Cache but the
+        // factor is small enough for a good part of it to stay there between the sweeps once beta_mid no longer pushes it out.  Measured, hint against
+        // none (profiles/studies/r04_nontemporal.txt): knot -2.5 % (everything fits), knot63 / sphere10k / a 10k torus +9 %, tori of 20k / 40k / 60k vertices
+        // +3.3 / +3.7 / +5.0 %, 80k +0.3 %, 100k -0.5 %; T = 63: 20k +2.3 %, 40k +0.1...1.5 %; T = 127: 20k -0.2...+1.7 %, 65k -2 %
+        // (the sweeps of the last four touch 0.92-3.1 GB): on up to 0.9 GB
         const double mall = 256.0 * 1048576.0, F8 = 8.0 * (double)c->d.F * (double)c->d.TP, V8 = 8.0 * (double)c->d.V * (double)c->d.TP;
         const double touched = 33.0 * F8 + 12.0 * V8;      // beta_mid, B, E, the carried sums; the vertex arrays
         int nt = -1;
         if (!env_int("DOTS_BM_NT", 0, 1, &nt)) { front_release(c); return DOTS_ERR_ARGUMENT; }
         const double factor = 0.5 * c->front_bytes;      // what the sweeps touch: every block is read by both sweeps (the zero blocks of merged nodes are never read)
-        c->bm_nt = nt >= 0 ? nt : (factor < 0.85 * mall && factor + touched > mall ? 1 : 0);
+        c->bm_nt = nt >= 0 ? nt : (factor < 0.9e9 && factor + touched > mall ? 1 : 0);
     }
     if (c->d.TP <= 128 && c->carry_arrays && c->d.nl > 0) {      // (one GPU or a time slab with nodes)
         const int64_t rows = (int64_t)3 * c->d.F;
@@ -1201,6 +1204,7 @@ int64_t dots_debug_counter(dots_ctx *c, int which) {
         case 3: return c->penalty_ahead_confirmed;
         case 4: return c->front.n_leaves;      // leaves the sweeps handle as explicit local inverses (0: band kernels)
         case 5: return c->front.leaf_bd ? 1 : 0;      // ... with their coupling in per-row records (0: read from the CSR)
+        case 6: return c->bm_nt;                      // beta_mid streamed around the caches by steps 2+3 (the rule of dots_front_setup, or DOTS_BM_NT)
         default: return -1;
     }
 }

@@ -491,7 +491,8 @@ int dots_bench_kernel(dots_ctx *ctx, int which, int reps, double *ms_per_launch,
  * device scalars instead: never stale), 1 mailbox hand-overs so far, 2 penalty decisions taken ahead of the host (dots_penalty_ahead), 3 those the
  * caller's own decision then confirmed, 4 tree leaves the sweeps of the direct solve handle as explicit local inverses
  * (0: the leaves' band runs in the band kernels), 5 whether those leaves take their coupling from per-row
- * records (1) or from the CSR of K (0: a row holds more entries than a record, or DOTS_FRONT_LEAFINV=2); -1 for an unknown counter */
+ * records (1) or from the CSR of K (0: a row holds more entries than a record, or DOTS_FRONT_LEAFINV=2), 6 whether steps 2+3 stream
+ * beta_mid with the non-temporal hint (decided by dots_front_setup from the sizes of factor and state); -1 for an unknown counter */
 int64_t dots_debug_counter(dots_ctx *ctx, int which);
 
 /* device memory in use by the context, bytes */

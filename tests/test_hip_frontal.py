@@ -346,3 +346,23 @@ def test_leaf_coupling_falls_back_to_the_csr_on_high_degree_vertices(monkeypatch
         dev.close()
     assert counters["1"][0] > 0 and counters["1"][1] == 0 and counters["0"] == (0, 0)
     assert np.all(np.isfinite(out["1"])) and rel(out["1"], out["0"]) < 1e-11
+
+
+@pytest.mark.parametrize("mesh,kw,T,want", [("knot", {}, 31, 0), ("knot", {}, 63, 1), ("sphere", dict(level=5), 31, 1), ("torus", dict(nu=250, nv=160), 31, 1),
+                                            ("torus", dict(nu=400, nv=250), 31, 0)])
+def test_beta_mid_streaming_rule(mesh, kw, T, want, monkeypatch):
+    """dots_front_setup decides per context whether steps 2+3 stream beta_mid with the non-temporal hint (Ctx::bm_nt; debug counter 6): not where
+    factor + state fit the 256 MB Infinity Cache (knot), not where the sweeps touch more than 0.9 GB (torus100k), in between yes; DOTS_BM_NT overrides.
+    (The iterates do not depend on it: test_hip_phases / test_hip_solver run with either setting.)"""
+    geom, _ = meshes.example(mesh, **kw)
+    for env, expect in ((None, want), ("0", 0), ("1", 1)):
+        if env is None:
+            monkeypatch.delenv("DOTS_BM_NT", raising=False)
+        else:
+            monkeypatch.setenv("DOTS_BM_NT", env)
+        dev = make(geom, T, 0.0, "nd")
+        dev.setup_frontal(eps=0.0)
+        assert dev.debug_counter(6) == expect
+        dev.close()
+        if mesh == "torus" and kw["nu"] == 400:
+            break      # (one setup of the large mesh is enough)
