@@ -472,8 +472,10 @@ def test_bench_launches_its_own_ranks(monkeypatch, capsys):
     args = bench.parse()
     assert bench.launch_ranks(args) == 0
     cmd = seen["cmd"]
-    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "2", "--steps", "20", "--warmup", "5"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    # (the launcher picks the rendezvous port itself, on the loopback address: no bind-and-close race, no host name to resolve)
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in cmd
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "20", "--warmup", "5"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     out = capsys.readouterr()
     assert out.out.strip() == '{"metric": "ALM iterations/s", "value": 1.0, "n_gpus": 2}' and "Gloo" in out.err
