@@ -483,6 +483,9 @@ __global__ __launch_bounds__(CG_NB) void k_collapse(const double *__restrict__ s
     }
 }
 
+// (Round 4: both stages in ONE launch -- the last workgroup to finish, by a ticket, adds the stage rows -- gives the same totals bit for bit and is
+// SLOWER: modal_pcg at torus100k 113.9 -> 99.5 it/s.  Even 64 agent-scope fences per launch write back and invalidate the L2s the
+// cache-resident PCG lives on; profiles/studies/r04_reduce_with_dual_alpha.txt has the same finding for the KKT reduction.  Not kept.)
 // One element per thread keeps the rows in flight per XCD well inside its L2 (measured: a 7-neighbour
 // gather at V = 100k takes 39 us with 1 element per thread and 56 us with 4, profiles/micro).  Up to 1024
 // workgroups their partial sums are re-reduced inside the consumer kernels; beyond that k_collapse does it.

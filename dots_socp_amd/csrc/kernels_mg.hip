@@ -125,6 +125,28 @@ __global__ __launch_bounds__(MG_NB) void k_mg_restrict(Dev d, MgLevelDev L, MgAr
     mg_restrict_elem(d, L, a, r, dKc, dMc, bc, btc, i, c);
 }
 
+// restriction onto a SMALL coarse level: a workgroup per coarse row, its ~20-60 entries split over the lanes that do not index the column
+// (one thread per (row, column) leaves a level of 200-2 000 rows with 26-250 workgroups each walking a whole row: 9.5-11 us at torus100k)
+__global__ __launch_bounds__(MG_NB) void k_mg_restrict_rows(Dev d, MgLevelDev L, MgArgs a, const double *__restrict__ r, const double *__restrict__ dKc,
+                                                          const double *__restrict__ dMc, double *__restrict__ bc, double *__restrict__ btc) {
+    __shared__ double red[MG_NB];
+    const int i = blockIdx.x, tid = threadIdx.x, sh = d.tp_shift;
+    const int c = tid & (d.TP - 1), q = tid >> sh, Q = MG_NB >> sh;
+    const bool live = c < a.ncol && !d.flags[c];
+    double s = 0.0;
+    if (live)
+        for (int j = L.r_rp[i] + q; j < L.r_rp[i + 1]; j += Q) s += L.r_val[j] * r[(L.r_col[j] << sh) + c];
+    red[tid] = s;
+    __syncthreads();
+    if (q == 0 && live) {
+        double t = 0.0;
+        for (int k = 0; k < Q; ++k) t += red[c + (k << sh)];
+        const int ic = (i << sh) + c;
+        bc[ic] = t;
+        btc[ic] = t / (dKc[i] + mg_shift(d, a, c) * dMc[i]);
+    }
+}
+
 __global__ __launch_bounds__(MG_NB) void k_mg_post(Dev d, MgLevelDev L, MgArgs a, const double *bt, const double *__restrict__ r,
                                                  const double *__restrict__ xc, double *z) {
     MG_THREAD_SETUP(L.n)
@@ -148,6 +170,28 @@ __global__ __launch_bounds__(MG_NB) void k_mg_coarse(Dev d, MgArgs a, int n, con
     }
     for (; j < n; ++j) s0 += row[(int64_t)j << sh] * b[(j << sh) + c];
     x[(i << sh) + c] = (s0 + s1) + (s2 + s3);
+}
+
+// the same with a workgroup per row, its dot product split over the lanes that do not index the column: a coarsest level of ~200 rows
+// is 26 workgroups of the kernel above (22 us at torus100k, each thread walking 208 entries) and ~200 of this one
+__global__ __launch_bounds__(MG_NB) void k_mg_coarse_rows(Dev d, MgArgs a, int n, const double *__restrict__ inv, const double *__restrict__ b,
+                                                        double *__restrict__ x) {
+    __shared__ double red[MG_NB];
+    const int i = blockIdx.x, tid = threadIdx.x, sh = d.tp_shift;
+    const int c = tid & (d.TP - 1), q = tid >> sh, Q = MG_NB >> sh;
+    const bool live = c < a.ncol && !d.flags[c];
+    double s = 0.0;
+    if (live) {
+        const double *row = inv + (((int64_t)i * n) << sh) + c;
+        for (int j = q; j < n; j += Q) s += row[(int64_t)j << sh] * b[(j << sh) + c];
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (q == 0 && live) {
+        double t = 0.0;
+        for (int k = 0; k < Q; ++k) t += red[c + (k << sh)];
+        x[(i << sh) + c] = t;
+    }
 }
 
 // ---- the coarse tail in one launch: one workgroup per time-mode column ------------------------------
@@ -258,13 +302,15 @@ int mg_vcycle(Ctx *c, const double *r, double *z, double *t0, double *rz_part, i
         const double *bt = (l == 0) ? z : L.bt;
         double *t = (l == 0) ? t0 : L.t;
         hipLaunchKernelGGL(k_mg_down, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, L, a, b, bt, t);
-        hipLaunchKernelGGL(k_mg_restrict, dim3(mg_grid(d, L.nc)), dim3(MG_NB), 0, c->stream, d, L, a, t, C.dK, C.dM, C.b, C.bt);
+        if (L.nc <= 4096 && d.TP <= MG_NB / 2) hipLaunchKernelGGL(k_mg_restrict_rows, dim3(L.nc), dim3(MG_NB), 0, c->stream, d, L, a, t, C.dK, C.dM, C.b, C.bt);
+        else hipLaunchKernelGGL(k_mg_restrict, dim3(mg_grid(d, L.nc)), dim3(MG_NB), 0, c->stream, d, L, a, t, C.dK, C.dM, C.b, C.bt);
     }
     // the tail (at least the dense coarsest solve): one workgroup per column; a large coarsest level on
     // its own is solved by the flat kernel instead (one thread per entry, coalesced over the columns)
     if (first_tail == nl - 1 && m.lv[nl - 1].n > 64) {
         const MgLevelDev &L = m.lv[nl - 1];
-        hipLaunchKernelGGL(k_mg_coarse, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, a, L.n, m.coarse_inv, L.b, L.bt);
+        if (d.TP <= MG_NB / 2) hipLaunchKernelGGL(k_mg_coarse_rows, dim3(L.n), dim3(MG_NB), 0, c->stream, d, a, L.n, m.coarse_inv, L.b, L.bt);
+        else hipLaunchKernelGGL(k_mg_coarse, dim3(mg_grid(d, L.n)), dim3(MG_NB), 0, c->stream, d, a, L.n, m.coarse_inv, L.b, L.bt);
     } else {
         MgTail T{};
         T.first = first_tail;
