@@ -31,10 +31,6 @@
 // the forward rows carry their first column, the backward columns their row ranges), the nodes below the band write
 // their updates into planes of the merged node (nodes whose boundaries do not meet share a plane), and a solve takes
 // 2 x (number of bands) launches.  numpy restatement: tests/frontal_cpu.py (merge, solve_merged).
-//
-// LEAVES AS LOCAL INVERSES (round 4).  A leaf's front holds original matrix entries only, so where the leaves' band is not merged a leaf stores
-// S = A_ss^-1 (packed lower triangle) instead of [L^-1 ; G] and both sweeps take its coupling to the boundary from the entries of K (the same for
-// every mode): k_front_leaf_fwd / _bwd below, a fifth of the factor's bytes less on a large mesh.
 #include "dots_dev.h"
 
 #include <algorithm>
