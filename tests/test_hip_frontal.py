@@ -366,3 +366,45 @@ def test_beta_mid_streaming_rule(mesh, kw, T, want, monkeypatch):
         dev.close()
         if mesh == "torus" and kw["nu"] == 400:
             break      # (one setup of the large mesh is enough)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_leaf_inverses_on_random_triangulations(seed, monkeypatch):
+    """Irregular meshes with a boundary (Delaunay triangulations of random points, lifted off the plane), random sizes, leaf sizes, time
+    grids and shifts: the leaves as local inverses solve the systems like the band kernels do."""
+    from scipy.spatial import Delaunay
+
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(150, 2500))
+    pts = rng.random((n, 2))
+    tri = Delaunay(pts).simplices.astype(np.int64)
+    e1, e2 = pts[tri[:, 1]] - pts[tri[:, 0]], pts[tri[:, 2]] - pts[tri[:, 0]]
+    area2 = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
+    tri = tri[np.abs(area2) > 1e-7]                                   # (slivers on the hull)
+    used = np.unique(tri)
+    remap = -np.ones(n, dtype=np.int64)
+    remap[used] = np.arange(used.size)
+    pts, tri = pts[used], remap[tri]
+    v = np.column_stack([pts, 0.2 * np.sin(3.0 * pts[:, 0]) * np.cos(2.0 * pts[:, 1])])
+    mu0 = 1.0 + pts[:, 0]
+    mu1 = 2.0 - pts[:, 1]
+    geom = dict(vertices=v, triangles=tri, mu0=mu0 / mu0.sum(), mu1=mu1 / mu1.sum())
+    T = int(rng.choice([5, 12, 31, 63]))
+    leaf = int(rng.choice([8, 16, 24]))
+    eps = float(rng.choice([0.0, 1e-2]))
+    monkeypatch.setenv("DOTS_FRONT_BANDS", "off")
+    out, leaves = {}, {}
+    for tag in ("1", "0"):
+        monkeypatch.setenv("DOTS_FRONT_LEAFINV", tag)
+        dev = make(geom, T, eps, "nd", nd_leaf=leaf)
+        dev.setup_frontal(eps=eps)
+        leaves[tag] = dev.debug_counter(4)
+        st = dev.run_phase("laplacian")
+        assert st.cg_not_converged == 0
+        phi = dev.download("phi")
+        assert np.all(np.isfinite(phi))
+        mass = dev.plan.mass_vert[np.argsort(dev.plan.perm_vert)]
+        out[tag] = gauge(phi, mass) if eps == 0.0 else phi
+        dev.close()
+    assert leaves["1"] > 0 and leaves["0"] == 0
+    assert rel(out["1"], out["0"]) < 1e-10
