@@ -89,6 +89,17 @@ def test_runs_match_reference(fname, lap_solver):
         assert rel(np.stack([c["mu"] for c in sol["checkpoints"]]), g["ckpt_mu"]) < 1e-5
 
 
+@pytest.mark.parametrize("fname", ["run_ico2_T15_cong_tol1e-3.npz", "run_refplane20_T31_tol1e-3.npz", "run_torus_T7_tol1e-4.npz"])
+def test_runs_match_reference_with_unmerged_tree_heights(fname, monkeypatch):
+    """One launch per tree height (DOTS_FRONT_BANDS=off) puts the leaves of these small meshes into their own band: the leaves are then
+    stored as explicit local inverses (kernels_front.hip: k_front_leaf_fwd / _bwd) -- the runs are the reference's all the same."""
+    monkeypatch.setenv("DOTS_FRONT_BANDS", "off")
+    g = golden(fname)
+    sol, hist = run_hip(g, lap_solver="modal_direct")
+    assert hist.solver_stats["cg_not_converged"] == 0
+    compare(g, sol, hist, REL_TOL)
+
+
 @pytest.mark.parametrize("fname", HEADLINE)
 def test_headline_runs(fname):
     """plane n=20, T=31, tol=1e-3: iteration index 361 / cost 4.00756e-2
